@@ -1,0 +1,126 @@
+/*
+ * isingmc_hip.h — C ABI of the MI355X-native SSE sweep engine (libisingmc_hip.so).
+ *
+ * The reference (Renmusxd/IsingMonteCarlo, crate `qmc`) is 100 % safe Rust with no FFI; its extension
+ * point is "implement the manager traits on your own container M and instantiate QmcIsingGraph<R,M> /
+ * Qmc<R,M>" (src/sse/qmc_ising.rs:20-23,80-91; src/sse/qmc_runner.rs:21).  A GPU manager cannot serve the
+ * per-slot closures of those traits across a device boundary, so the boundary sits at the sweep-level
+ * default methods, batch-first (one handle = R independent replicas, as ParallelQmcTimeSteps treats
+ * graphs: src/sse/parallel_tempering/tempering_container.rs:321-340).  Each entry point below names the
+ * reference interface it replaces.  The Rust-side binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions: every function returns 0 on success, a negative ISINGMC_E* code otherwise; the message is
+ * available from isingmc_last_error().  Array arguments are borrowed for the duration of the call; outputs
+ * are caller-allocated.  A handle may be moved between host threads but used by one at a time (!Sync),
+ * matching `&mut self` on every reference update.  There is NO CPU fallback: without a HIP device
+ * isingmc_create fails with ISINGMC_ENODEVICE.
+ */
+#ifndef ISINGMC_HIP_H
+#define ISINGMC_HIP_H
+
+#include <stdint.h>
+#include "sse_format.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISINGMC_OK 0
+#define ISINGMC_EINVAL (-1)    /* bad argument (maps the reference's Result<(),String> errors) */
+#define ISINGMC_ENODEVICE (-2) /* no usable HIP device / HIP runtime error */
+#define ISINGMC_ECAPACITY (-3) /* cutoff would exceed the preallocated op-string capacity */
+#define ISINGMC_EINTEGRITY (-4) /* device-side integrity failure (the reference would panic) */
+#define ISINGMC_ENOTIMPL (-5)
+
+/* update flags (isingmc_timesteps / isingmc_timestep) */
+#define ISINGMC_FLAG_LOOP 1u       /* Qmc::set_do_loop_updates(true): one directed loop per step (qmc_runner.rs:268,366) */
+#define ISINGMC_FLAG_NO_CLUSTER 2u /* skip the cluster step */
+#define ISINGMC_FLAG_HEATBATH 4u   /* set_enable_heatbath(true) (qmc_ising.rs:444) / set_do_heatbath (qmc_runner.rs:258) */
+#define ISINGMC_FLAG_RVB 8u        /* set_run_rvb(true) (qmc_ising.rs:435) */
+
+typedef struct isingmc_batch isingmc_batch;
+
+typedef struct isingmc_config {
+    uint32_t struct_size;     /* = sizeof(isingmc_config) */
+    uint32_t nreplicas;       /* R independent replicas resident on this device */
+    uint32_t nvars;           /* N (reference: max edge index + 1, qmc_ising.rs:92) */
+    uint32_t nedges;          /* E */
+    const uint32_t *edges;    /* [2E]: a0,b0,a1,b1,...  (Vec<(Edge,f64)>, qmc_ising.rs:81) */
+    const double *J;          /* [E]  couplings, J>0 antiferromagnetic (src/lib.rs:29) */
+    double transverse;        /* Gamma */
+    double longitudinal;      /* h */
+    uint32_t capacity;        /* op-string slots preallocated per replica (>= cutoff0) */
+    uint32_t cutoff0;         /* initial cutoff (QmcIsingGraph::new_with_rng `cutoff`) */
+    uint64_t seed;            /* Philox key; replaces the reference's `rng` argument */
+    uint32_t replica_offset;  /* global index of local replica 0 (replica sharding over GPUs) */
+    int32_t device;           /* HIP device ordinal, -1 = current device */
+    const uint8_t *init_state; /* [R][N] 0/1 or NULL = random (make_random_spin_state, classical/graph.rs:451) */
+    uint32_t waves_per_replica; /* 0 = auto; workgroup = this many wave64s cooperating on one replica */
+    uint32_t reserved;
+} isingmc_config;
+
+/* QmcIsingGraph::new_with_rng (qmc_ising.rs:131-148) + OpContainerConstructor::new_with_bonds
+ * (op_container.rs:110), for R replicas at once. */
+int isingmc_create(const isingmc_config *cfg, isingmc_batch **out);
+/* Drop */
+void isingmc_destroy(isingmc_batch *b);
+/* error text of the last failing call on this handle (b may be NULL: last isingmc_create failure) */
+const char *isingmc_last_error(const isingmc_batch *b);
+
+/* DiagonalUpdater::make_diagonal_update_with_rng_and_state_ref (qmc_traits/diagonal.rs:114-135), or with
+ * ISINGMC_FLAG_HEATBATH HeatBathDiagonalUpdater::make_heatbath_diagonal_update_with_rng_and_state_ref
+ * (qmc_traits/heatbath.rs:106-127).  beta[R].  Also applies cutoff = max(cutoff, n + n/2)
+ * (qmc_ising.rs:269,786; qmc_runner.rs:197). */
+int isingmc_diagonal_update(isingmc_batch *b, const double *beta, uint32_t flags);
+/* ClusterUpdater::flip_each_cluster_rng (qmc_traits/cluster.rs:36-172) with the weight function of
+ * qmc_ising.rs:759-775.  n_clusters[R] may be NULL. */
+int isingmc_cluster_update(isingmc_batch *b, double prob, uint32_t *n_clusters);
+/* LoopUpdater::make_loop_update_with_rng (qmc_traits/directed_loop.rs:103-171); lengths[R] may be NULL. */
+int isingmc_loop_update(isingmc_batch *b, uint32_t *lengths);
+/* qmc_ising.rs:780-784 / Qmc::flip_free_bits (qmc_runner.rs:241-255) */
+int isingmc_flip_free_spins(isingmc_batch *b);
+/* QmcStepper::timesteps_measure_with_self (qmc_traits/qmc_stepper.rs:133-162) over
+ * QmcIsingGraph::timestep (qmc_ising.rs:644-795) / Qmc::timestep (qmc_runner.rs:363-377), fused on device:
+ * t steps, sampling when (step+1) % sampling_freq == 0, accumulating into the per-replica accumulators. */
+int isingmc_timesteps(isingmc_batch *b, uint64_t t, const double *beta, uint32_t sampling_freq, uint32_t flags);
+
+/* accumulators [R][8] (u64): 0 sum n, 1 samples, 2 sum |2up-N|, 3 sum (2up-N)^2, 4 vertices visited by
+ * off-diagonal passes, 5 slots visited by diagonal passes, 6 sum of transverse-op counts, 7 reserved.
+ * Energy: QmcStepper::get_energy_for_average_n (qmc_ising.rs:805-809) = -(acc0/acc1)/beta + offset. */
+int isingmc_get_accumulators(isingmc_batch *b, uint64_t *out);
+int isingmc_reset_accumulators(isingmc_batch *b);
+/* QmcIsingGraph::get_offset (qmc_ising.rs:558) */
+double isingmc_get_offset(const isingmc_batch *b);
+uint32_t isingmc_num_bonds(const isingmc_batch *b);
+
+/* state_ref / clone_state / state_mut (qmc_ising.rs:497-509,797): out/in are [N] bytes 0/1 of replica r;
+ * r == UINT32_MAX addresses all replicas, buffers are then [R][N]. */
+int isingmc_get_state(isingmc_batch *b, uint32_t r, uint8_t *out);
+int isingmc_set_state(isingmc_batch *b, uint32_t r, const uint8_t *in);
+/* OpContainer::get_n / get_cutoff / set_cutoff (qmc_traits/op_container.rs:119-123), out[R] */
+int isingmc_get_n(isingmc_batch *b, uint32_t *out);
+int isingmc_get_cutoff(isingmc_batch *b, uint32_t *out);
+int isingmc_set_cutoff(isingmc_batch *b, uint32_t r, uint32_t cutoff);
+int isingmc_get_epoch(isingmc_batch *b, uint64_t *out);
+/* OpContainer::get_count (op_container.rs:129; fast_ops.rs:1281-1294) */
+int isingmc_get_bond_count(isingmc_batch *b, uint32_t r, uint32_t bond, uint32_t *out);
+/* get_pth for every p (op_container.rs:127): words[cutoff] in the sse_format.h encoding */
+int isingmc_export_ops(isingmc_batch *b, uint32_t r, uint32_t *words, uint32_t nwords);
+/* FastOps::new_from_ops (fast_ops.rs:80-174): install an op-string (words[nwords], slot p = index) */
+int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint32_t nwords);
+/* Verify::verify (qmc_ising.rs:829-860; op_container.rs:137-159), ok[R] */
+int isingmc_verify(isingmc_batch *b, uint8_t *ok);
+
+/* stream plumbing: use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+int isingmc_set_stream(isingmc_batch *b, void *hip_stream);
+int isingmc_synchronize(isingmc_batch *b);
+/* HIP-event timing of the most recent isingmc_timesteps launch(es): total ms and number of kernel launches */
+int isingmc_last_kernel_ms(isingmc_batch *b, float *ms, uint32_t *launches);
+/* build/launch configuration actually in use: out[0]=waves per replica, out[1]=dynamic LDS bytes,
+ * out[2]=union-find ids that fit in LDS, out[3]=state words per replica */
+int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISINGMC_HIP_H */

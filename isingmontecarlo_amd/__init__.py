@@ -1,0 +1,337 @@
+"""isingmontecarlo_amd — MI355X-native SSE sweep for transverse-field Ising models.
+
+Host-side mirror (Python, over the C ABI in include/isingmc_hip.h) of the reference crate's drivers for
+the SSE hot path: `QmcIsingGraph` (src/sse/qmc_ising.rs) and `Qmc` (src/sse/qmc_runner.rs), batch-first:
+one object = R independent replicas resident on one GPU.  All Monte-Carlo arithmetic runs in hand-written
+gfx950 kernels (csrc/); there is no CPU fallback — constructing a graph without a HIP device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+__all__ = ["QmcIsingGraph", "Qmc", "IsingMcError", "load_library", "op_make", "op_fields",
+           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB"]
+
+FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
+ALL = 0xFFFFFFFF
+
+_ERRNAMES = {-1: "EINVAL", -2: "ENODEVICE", -3: "ECAPACITY", -4: "EINTEGRITY", -5: "ENOTIMPL"}
+
+
+class IsingMcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"isingmc {_ERRNAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("nreplicas", C.c_uint32), ("nvars", C.c_uint32),
+                ("nedges", C.c_uint32), ("edges", C.POINTER(C.c_uint32)), ("J", C.POINTER(C.c_double)),
+                ("transverse", C.c_double), ("longitudinal", C.c_double), ("capacity", C.c_uint32),
+                ("cutoff0", C.c_uint32), ("seed", C.c_uint64), ("replica_offset", C.c_uint32),
+                ("device", C.c_int32), ("init_state", C.POINTER(C.c_uint8)),
+                ("waves_per_replica", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/isingmc_hip.h declares: name -> (restype, argtypes)
+_vp, _u32, _u64, _f64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_double
+_P = C.POINTER
+SYMBOLS = {
+    "isingmc_create": (C.c_int, [_P(_Config), _P(_vp)]),
+    "isingmc_destroy": (None, [_vp]),
+    "isingmc_last_error": (C.c_char_p, [_vp]),
+    "isingmc_diagonal_update": (C.c_int, [_vp, _P(_f64), _u32]),
+    "isingmc_cluster_update": (C.c_int, [_vp, _f64, _P(_u32)]),
+    "isingmc_loop_update": (C.c_int, [_vp, _P(_u32)]),
+    "isingmc_flip_free_spins": (C.c_int, [_vp]),
+    "isingmc_timesteps": (C.c_int, [_vp, _u64, _P(_f64), _u32, _u32]),
+    "isingmc_get_accumulators": (C.c_int, [_vp, _P(_u64)]),
+    "isingmc_reset_accumulators": (C.c_int, [_vp]),
+    "isingmc_get_offset": (_f64, [_vp]),
+    "isingmc_num_bonds": (_u32, [_vp]),
+    "isingmc_get_state": (C.c_int, [_vp, _u32, _P(C.c_uint8)]),
+    "isingmc_set_state": (C.c_int, [_vp, _u32, _P(C.c_uint8)]),
+    "isingmc_get_n": (C.c_int, [_vp, _P(_u32)]),
+    "isingmc_get_cutoff": (C.c_int, [_vp, _P(_u32)]),
+    "isingmc_set_cutoff": (C.c_int, [_vp, _u32, _u32]),
+    "isingmc_get_epoch": (C.c_int, [_vp, _P(_u64)]),
+    "isingmc_get_bond_count": (C.c_int, [_vp, _u32, _u32, _P(_u32)]),
+    "isingmc_export_ops": (C.c_int, [_vp, _u32, _P(_u32), _u32]),
+    "isingmc_import_ops": (C.c_int, [_vp, _u32, _P(_u32), _u32]),
+    "isingmc_verify": (C.c_int, [_vp, _P(C.c_uint8)]),
+    "isingmc_set_stream": (C.c_int, [_vp, _vp]),
+    "isingmc_synchronize": (C.c_int, [_vp]),
+    "isingmc_last_kernel_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
+    "isingmc_get_launch_info": (C.c_int, [_vp, _P(_u32)]),
+}
+
+_LIB = None
+
+
+def load_library(build=True):
+    """dlopen the in-tree libisingmc_hip.so (building it first if stale) and bind every symbol."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if build:
+        path = _build.build()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -m isingmontecarlo_amd._build` (no CPU fallback exists)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def op_make(bond, in_bits, out_bits):
+    """Encode one operator word (include/sse_format.h)."""
+    return ((bond + 1) << 4) | (in_bits & 3) | ((out_bits & 3) << 2)
+
+
+def op_fields(word):
+    """Decode an operator word -> (bond, in_bits, out_bits) or None for the identity."""
+    if word == 0:
+        return None
+    return (int(word) >> 4) - 1, int(word) & 3, (int(word) >> 2) & 3
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class QmcIsingGraph:
+    """Batch of R transverse-field Ising SSE graphs on one GPU.
+
+    Mirrors qmc::sse::QmcIsingGraph (src/sse/qmc_ising.rs): `edges` is a list of ((a, b), J) like the
+    reference's Vec<(Edge, f64)>; `seed` replaces the `rng` argument (counter-based Philox on device).
+    """
+
+    def __init__(self, edges, transverse, longitudinal, cutoff, seed, state=None, nreplicas=1,
+                 capacity=None, replica_offset=0, device=-1, waves_per_replica=0):
+        lib = load_library()
+        self._lib = lib
+        self._h = None
+        ed = np.ascontiguousarray(np.array([[a, b] for (a, b), _ in edges], dtype=np.uint32))
+        js = np.ascontiguousarray(np.array([j for _, j in edges], dtype=np.float64))
+        if len(ed) == 0:
+            raise IsingMcError(-1, "at least one edge is required")
+        self.nvars = int(ed.max()) + 1  # qmc_ising.rs:92
+        self.nreplicas = int(nreplicas)
+        self.transverse, self.longitudinal = float(transverse), float(longitudinal)
+        self.edges, self.J = ed, js
+        if capacity is None:
+            capacity = max(int(cutoff), 64)
+        init = None
+        if state is not None:
+            st = np.asarray(state, dtype=np.uint8)
+            if st.ndim == 1:
+                st = np.broadcast_to(st, (self.nreplicas, self.nvars))
+            init = np.ascontiguousarray(st)
+            if init.shape != (self.nreplicas, self.nvars):
+                raise IsingMcError(-1, "initial state has the wrong shape")
+        cfg = _Config(struct_size=C.sizeof(_Config), nreplicas=self.nreplicas, nvars=self.nvars, nedges=len(js),
+                      edges=_ptr(ed, C.c_uint32), J=_ptr(js, C.c_double), transverse=self.transverse,
+                      longitudinal=self.longitudinal, capacity=int(capacity), cutoff0=int(cutoff), seed=int(seed),
+                      replica_offset=int(replica_offset), device=int(device),
+                      init_state=_ptr(init, C.c_uint8) if init is not None else None,
+                      waves_per_replica=int(waves_per_replica), reserved=0)
+        h = C.c_void_p()
+        rc = lib.isingmc_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise IsingMcError(rc, lib.isingmc_last_error(None).decode())
+        self._h = h
+        self.capacity = int(capacity)
+        self._flags = 0
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.isingmc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise IsingMcError(rc, self._lib.isingmc_last_error(self._h).decode())
+
+    def _betas(self, beta):
+        b = np.ascontiguousarray(np.broadcast_to(np.asarray(beta, dtype=np.float64), (self.nreplicas,)))
+        return b
+
+    # ---- toggles (qmc_ising.rs:435,444) ----
+    def set_enable_heatbath(self, enable):
+        self._flags = (self._flags | FLAG_HEATBATH) if enable else (self._flags & ~FLAG_HEATBATH)
+
+    def set_run_rvb(self, run_rvb):
+        self._flags = (self._flags | FLAG_RVB) if run_rvb else (self._flags & ~FLAG_RVB)
+
+    # ---- updates ----
+    def timestep(self, beta):
+        """QmcStepper::timestep (qmc_ising.rs:644): one sweep of every replica; returns the p=0 states."""
+        self.timesteps(1, beta)
+        return self.state_ref()
+
+    def timesteps(self, t, beta, sampling_freq=1, flags=None):
+        """QmcStepper::timesteps (qmc_stepper.rs:17-20): returns the energy estimate per replica."""
+        f = self._flags if flags is None else flags
+        self.reset_accumulators()
+        b = self._betas(beta)
+        self._check(self._lib.isingmc_timesteps(self._h, int(t), _ptr(b, C.c_double), int(sampling_freq), f))
+        acc = self.accumulators()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            avg_n = acc[:, 0] / acc[:, 1]
+        return self.get_energy_for_average_n(avg_n, b)
+
+    def run(self, t, beta, sampling_freq=1, flags=None):
+        """timesteps without touching the accumulators (they keep summing)."""
+        f = self._flags if flags is None else flags
+        b = self._betas(beta)
+        self._check(self._lib.isingmc_timesteps(self._h, int(t), _ptr(b, C.c_double), int(sampling_freq), f))
+
+    def single_diagonal_step(self, beta):
+        """qmc_ising.rs:208-272"""
+        b = self._betas(beta)
+        self._check(self._lib.isingmc_diagonal_update(self._h, _ptr(b, C.c_double), self._flags & FLAG_HEATBATH))
+
+    def single_cluster_step(self, prob=0.5, flip_free=True):
+        """qmc_ising.rs:275-320: cluster flips then free-spin randomisation; returns the cluster counts."""
+        out = np.zeros(self.nreplicas, dtype=np.uint32)
+        self._check(self._lib.isingmc_cluster_update(self._h, float(prob), _ptr(out, C.c_uint32)))
+        if flip_free:
+            self._check(self._lib.isingmc_flip_free_spins(self._h))
+        return out
+
+    def loop_update(self):
+        out = np.zeros(self.nreplicas, dtype=np.uint32)
+        self._check(self._lib.isingmc_loop_update(self._h, _ptr(out, C.c_uint32)))
+        return out
+
+    def flip_free_spins(self):
+        self._check(self._lib.isingmc_flip_free_spins(self._h))
+
+    # ---- observables / accessors ----
+    def accumulators(self):
+        out = np.zeros((self.nreplicas, 8), dtype=np.uint64)
+        self._check(self._lib.isingmc_get_accumulators(self._h, _ptr(out, C.c_uint64)))
+        return out
+
+    def reset_accumulators(self):
+        self._check(self._lib.isingmc_reset_accumulators(self._h))
+
+    def get_offset(self):
+        return self._lib.isingmc_get_offset(self._h)
+
+    def get_energy_for_average_n(self, average_n, beta):
+        """qmc_ising.rs:805-809"""
+        return -(np.asarray(average_n, dtype=np.float64) / beta) + self.get_offset()
+
+    def num_bonds(self):
+        return self._lib.isingmc_num_bonds(self._h)
+
+    def state_ref(self):
+        out = np.zeros((self.nreplicas, self.nvars), dtype=np.uint8)
+        self._check(self._lib.isingmc_get_state(self._h, ALL, _ptr(out, C.c_uint8)))
+        return out
+
+    clone_state = state_ref
+
+    def set_state(self, state, r=None):
+        st = np.ascontiguousarray(np.asarray(state, dtype=np.uint8))
+        self._check(self._lib.isingmc_set_state(self._h, ALL if r is None else int(r), _ptr(st, C.c_uint8)))
+
+    def _u32(self, fn):
+        out = np.zeros(self.nreplicas, dtype=np.uint32)
+        self._check(fn(self._h, _ptr(out, C.c_uint32)))
+        return out
+
+    def get_n(self):
+        return self._u32(self._lib.isingmc_get_n)
+
+    def get_cutoff(self):
+        return self._u32(self._lib.isingmc_get_cutoff)
+
+    def set_cutoff(self, cutoff, r=None):
+        for i in (range(self.nreplicas) if r is None else [int(r)]):
+            self._check(self._lib.isingmc_set_cutoff(self._h, i, int(cutoff)))
+
+    def get_epoch(self):
+        out = np.zeros(self.nreplicas, dtype=np.uint64)
+        self._check(self._lib.isingmc_get_epoch(self._h, _ptr(out, C.c_uint64)))
+        return out
+
+    def get_bond_count(self, bond, r=0):
+        out = C.c_uint32(0)
+        self._check(self._lib.isingmc_get_bond_count(self._h, int(r), int(bond), C.byref(out)))
+        return out.value
+
+    def export_ops(self, r=0, nwords=None):
+        if nwords is None:
+            nwords = int(self.get_cutoff()[r])
+        out = np.zeros(nwords, dtype=np.uint32)
+        self._check(self._lib.isingmc_export_ops(self._h, int(r), _ptr(out, C.c_uint32), int(nwords)))
+        return out
+
+    def import_ops(self, words, r=0):
+        w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
+        self._check(self._lib.isingmc_import_ops(self._h, int(r), _ptr(w, C.c_uint32), len(w)))
+
+    def verify(self):
+        out = np.zeros(self.nreplicas, dtype=np.uint8)
+        self._check(self._lib.isingmc_verify(self._h, _ptr(out, C.c_uint8)))
+        return out.astype(bool)
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.isingmc_set_stream(self._h, C.c_void_p(int(stream_ptr))))
+
+    def synchronize(self):
+        self._check(self._lib.isingmc_synchronize(self._h))
+
+    def last_kernel_ms(self):
+        ms, n = C.c_float(0), C.c_uint32(0)
+        self._check(self._lib.isingmc_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def launch_info(self):
+        out = (C.c_uint32 * 4)()
+        self._check(self._lib.isingmc_get_launch_info(self._h, out))
+        return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3])
+
+    def into_qmc(self, do_loop_updates=False):
+        """IntoQmc::into_qmc (qmc_ising.rs:943-976): same container driven through Qmc::timestep."""
+        q = Qmc.__new__(Qmc)
+        q.__dict__ = self.__dict__
+        q._flags = (self._flags & FLAG_HEATBATH) | (FLAG_LOOP if do_loop_updates else 0)
+        self._h = None
+        return q
+
+
+class Qmc(QmcIsingGraph):
+    """qmc::sse::Qmc (src/sse/qmc_runner.rs) restricted to Ising interactions: timestep =
+    diagonal -> [directed loop] -> cluster -> free spins (qmc_runner.rs:363-377)."""
+
+    def set_do_loop_updates(self, do_loop_updates):
+        self._flags = (self._flags | FLAG_LOOP) if do_loop_updates else (self._flags & ~FLAG_LOOP)
+
+    def should_do_loop_update(self):
+        return bool(self._flags & FLAG_LOOP)
+
+    def set_do_heatbath(self, do_heatbath):
+        self.set_enable_heatbath(do_heatbath)
+
+    def diagonal_update(self, beta):
+        self.single_diagonal_step(beta)
+
+    def cluster_update(self):
+        return self.single_cluster_step(flip_free=False)
+
+    def flip_free_bits(self):
+        self.flip_free_spins()

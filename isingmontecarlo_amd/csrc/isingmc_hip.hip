@@ -1,0 +1,426 @@
+// isingmc_hip.hip — C ABI (include/isingmc_hip.h) over the gfx950 kernels of sse_device.hip.h.
+// Host side only sequences launches and moves small control arrays; there is no CPU compute fallback.
+#include "../../include/isingmc_hip.h"
+#include "sse_device.hip.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sse;
+
+static thread_local std::string g_create_error;
+
+struct isingmc_batch {
+    DevBatch dev{};
+    uint32_t W = 8;
+    size_t lds_bytes = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    uint32_t last_launches = 0;
+    double offset = 0.0;
+    std::vector<BondRec> bonds_host;
+    double *d_beta = nullptr;
+    uint32_t *d_out = nullptr;
+    uint32_t *d_vstate = nullptr;
+    uint8_t *d_ok = nullptr;
+    std::vector<void *> allocs;
+    mutable std::string err;
+};
+
+#define HIP_TRY(b, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (b)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                             \
+            return ISINGMC_ENODEVICE;                                                                 \
+        }                                                                                             \
+    } while (0)
+
+template <typename T>
+static int dalloc(isingmc_batch *b, T **p, size_t count, bool zero = true) {
+    void *q = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(b, hipMalloc(&q, bytes));
+    b->allocs.push_back(q);
+    if (zero) HIP_TRY(b, hipMemset(q, 0, bytes));
+    *p = reinterpret_cast<T *>(q);
+    return ISINGMC_OK;
+}
+
+__global__ void init_state_kernel(DevBatch B) {
+    // classical/graph.rs:451-453 make_random_spin_state: one fair bit per variable (Philox tag INIT, epoch 0)
+    const uint32_t r = blockIdx.x;
+    const Rng rng = make_rng(B, r, 0ull);
+    for (uint32_t i = threadIdx.x; i < B.nwords; i += blockDim.x) {
+        uint32_t s = 0;
+        for (uint32_t j = 0; j < 32 && i * 32 + j < B.N; ++j) s |= (rng.draw(SSE_TAG_INIT, i * 32 + j).x >> 31) << j;
+        B.state[(size_t)r * B.nwords + i] = s;
+    }
+}
+
+static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords) {
+    return (size_t)nwords * (W + 2) + 4 * W + 16 + (size_t)W * N;
+}
+
+template <int W>
+static hipError_t launch_sweep(isingmc_batch *b, const SweepArgs &A) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel<W>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sweep_kernel<W>, dim3(b->dev.R), dim3(W * 64), b->lds_bytes, b->stream, b->dev, A);
+    return hipGetLastError();
+}
+
+static int check_errors(isingmc_batch *b) {
+    std::vector<uint32_t> err(b->dev.R);
+    HIP_TRY(b, hipMemcpyAsync(err.data(), b->dev.err, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    for (uint32_t r = 0; r < b->dev.R; ++r)
+        if (err[r]) {
+            char buf[160];
+            if (err[r] == 1u) {
+                snprintf(buf, sizeof buf, "replica %u: cutoff n + n/2 exceeds the op-string capacity %u", r, b->dev.cap);
+                b->err = buf;
+                return ISINGMC_ECAPACITY;
+            }
+            snprintf(buf, sizeof buf, "replica %u: device integrity error %u", r, err[r]);
+            b->err = buf;
+            return ISINGMC_EINTEGRITY;
+        }
+    return ISINGMC_OK;
+}
+
+static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t freq, uint32_t domask, double prob,
+               uint32_t *out_host) {
+    if (!b) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    SweepArgs A{};
+    A.beta = nullptr;
+    if (beta) {
+        for (uint32_t r = 0; r < b->dev.R; ++r)
+            if (!(beta[r] >= 0.0) || !std::isfinite(beta[r])) { b->err = "beta must be finite and >= 0"; return ISINGMC_EINVAL; }
+        HIP_TRY(b, hipMemcpyAsync(b->d_beta, beta, sizeof(double) * b->dev.R, hipMemcpyHostToDevice, b->stream));
+        A.beta = b->d_beta;
+    } else if (domask & SSE_DO_DIAG) {
+        b->err = "beta is required for a diagonal update";
+        return ISINGMC_EINVAL;
+    }
+    A.nsteps = nsteps;
+    A.sampling_freq = freq;
+    A.domask = domask;
+    A.prob = prob;
+    A.out_u32 = out_host ? b->d_out : nullptr;
+    HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
+    hipError_t e;
+    switch (b->W) {
+    case 1: e = launch_sweep<1>(b, A); break;
+    case 2: e = launch_sweep<2>(b, A); break;
+    case 4: e = launch_sweep<4>(b, A); break;
+    case 8: e = launch_sweep<8>(b, A); break;
+    case 16: e = launch_sweep<16>(b, A); break;
+    default: b->err = "unsupported waves_per_replica"; return ISINGMC_EINVAL;
+    }
+    if (e != hipSuccess) { b->err = std::string("sweep launch: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; }
+    HIP_TRY(b, hipEventRecord(b->ev1, b->stream));
+    int rc = check_errors(b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) { b->last_ms = ms; b->last_launches = 1; }
+    if (rc) return rc;
+    if (out_host) HIP_TRY(b, hipMemcpy(out_host, b->d_out, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost));
+    return ISINGMC_OK;
+}
+
+extern "C" {
+
+int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
+    if (!cfg || !out || cfg->struct_size != sizeof(isingmc_config)) { g_create_error = "bad config pointer or struct_size"; return ISINGMC_EINVAL; }
+    *out = nullptr;
+    if (cfg->nreplicas == 0 || cfg->nvars == 0 || cfg->nedges == 0 || !cfg->edges || !cfg->J) { g_create_error = "nreplicas, nvars, nedges must be > 0 and edges/J non-null"; return ISINGMC_EINVAL; }
+    if (cfg->cutoff0 > cfg->capacity) { g_create_error = "cutoff0 exceeds capacity"; return ISINGMC_EINVAL; }
+    if (cfg->nvars > SSE_VAR_MASK) { g_create_error = "too many variables"; return ISINGMC_EINVAL; }
+    if (!(cfg->transverse >= 0.0)) { g_create_error = "transverse field must be >= 0"; return ISINGMC_EINVAL; }
+    for (uint32_t e = 0; e < cfg->nedges; ++e)
+        if (cfg->edges[2 * e] >= cfg->nvars || cfg->edges[2 * e + 1] >= cfg->nvars || cfg->edges[2 * e] == cfg->edges[2 * e + 1]) {
+            g_create_error = "edge endpoint out of range";
+            return ISINGMC_EINVAL;
+        }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (this library has no CPU fallback)"; return ISINGMC_ENODEVICE; }
+    isingmc_batch *b = new isingmc_batch();
+    int dev = cfg->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    b->device = dev;
+    auto fail = [&](int rc) { g_create_error = b->err; isingmc_destroy(b); return rc; };
+    if (hipSetDevice(dev) != hipSuccess) { b->err = "hipSetDevice failed"; return fail(ISINGMC_ENODEVICE); }
+
+    DevBatch &D = b->dev;
+    const bool has_long = std::fabs(cfg->longitudinal) > DBL_EPSILON; // qmc_ising.rs:230
+    D.R = cfg->nreplicas; D.N = cfg->nvars; D.E = cfg->nedges;
+    D.Nb = cfg->nedges + cfg->nvars + (has_long ? cfg->nvars : 0);
+    if (D.Nb > SSE_MAX_BONDS) { b->err = "too many bonds"; return fail(ISINGMC_EINVAL); }
+    D.cap = cfg->capacity; D.nwords = (cfg->nvars + 31) / 32;
+    D.seed_lo = (uint32_t)cfg->seed; D.seed_hi = (uint32_t)(cfg->seed >> 32);
+    D.replica_offset = cfg->replica_offset;
+
+    // bond table (qmc_ising.rs:186-205,228-246; weights :863-888; offsets :97-99)
+    std::vector<BondRec> &tab = b->bonds_host;
+    tab.resize(D.Nb);
+    std::vector<double> cum(D.Nb);
+    double off = 0.0;
+    for (uint32_t e = 0; e < D.E; ++e) {
+        const double J = cfg->J[e];
+        tab[e].a_info = cfg->edges[2 * e] | ((SSE_BOND_TWO_SITE | (J < 0.0 ? SSE_BOND_PREF_BIT : 0u)) << SSE_INFO_SHIFT);
+        tab[e].c = cfg->edges[2 * e + 1];
+        tab[e].w = 2.0 * std::fabs(J);
+        off += std::fabs(J);
+    }
+    for (uint32_t v = 0; v < D.N; ++v) {
+        BondRec &t = tab[D.E + v];
+        t.a_info = v | (SSE_BOND_TRANSVERSE << SSE_INFO_SHIFT); t.c = SSE_NO_VAR; t.w = cfg->transverse;
+    }
+    if (has_long)
+        for (uint32_t v = 0; v < D.N; ++v) {
+            BondRec &t = tab[D.E + D.N + v];
+            t.a_info = v | ((SSE_BOND_LONGITUDINAL | (cfg->longitudinal > 0.0 ? SSE_BOND_PREF_BIT : 0u)) << SSE_INFO_SHIFT);
+            t.c = SSE_NO_VAR; t.w = 2.0 * std::fabs(cfg->longitudinal);
+        }
+    b->offset = off + (double)D.N * (cfg->transverse + std::fabs(cfg->longitudinal));
+    double c = 0.0;
+    for (uint32_t i = 0; i < D.Nb; ++i) { c = (i == 0) ? tab[0].w : tab[i].w + c; cum[i] = c; }
+    D.wtot = c;
+
+    // launch geometry: W waves per replica, all of LDS for one workgroup
+    int max_lds = 0;
+    if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || max_lds <= 0) max_lds = 65536;
+    const size_t total_words = (size_t)max_lds / 4;
+    uint32_t W = cfg->waves_per_replica ? cfg->waves_per_replica : 8;
+    if (W != 1 && W != 2 && W != 4 && W != 8 && W != 16) { b->err = "waves_per_replica must be 1,2,4,8 or 16"; return fail(ISINGMC_EINVAL); }
+    while (W > 1 && lds_fixed_words(W, D.N, D.nwords) + 4096 > total_words) W >>= 1;
+    const size_t fixed = lds_fixed_words(W, D.N, D.nwords);
+    if (fixed + 64 > total_words) { b->err = "model too large: per-variable scan tables do not fit in LDS"; return fail(ISINGMC_ENOTIMPL); }
+    const size_t remaining = total_words - fixed;
+    size_t ufcap = (remaining - 2) * 32 / 34;
+    const size_t ids_max = (size_t)D.N + D.cap;
+    if (ufcap > ids_max) ufcap = ids_max;
+    D.lds_ufcap = (uint32_t)ufcap;
+    b->W = W;
+    b->lds_bytes = 4 * (fixed + ufcap + 2 * ((ufcap + 31) / 32));
+
+    int rc;
+    if ((rc = dalloc(b, &D.ops, (size_t)D.R * D.cap))) return fail(rc);
+    if ((rc = dalloc(b, &D.state, (size_t)D.R * D.nwords))) return fail(rc);
+    if ((rc = dalloc(b, &D.n, D.R))) return fail(rc);
+    if ((rc = dalloc(b, &D.ntrans, D.R))) return fail(rc);
+    if ((rc = dalloc(b, &D.cutoff, D.R))) return fail(rc);
+    if ((rc = dalloc(b, &D.err, D.R))) return fail(rc);
+    if ((rc = dalloc(b, &D.aux, D.R))) return fail(rc);
+    if ((rc = dalloc(b, &D.epoch, D.R))) return fail(rc);
+    if ((rc = dalloc(b, &D.acc, (size_t)D.R * 8))) return fail(rc);
+    BondRec *dbonds = nullptr; double *dcum = nullptr;
+    if ((rc = dalloc(b, &dbonds, D.Nb, false))) return fail(rc);
+    if ((rc = dalloc(b, &dcum, D.Nb, false))) return fail(rc);
+    D.bonds = dbonds; D.cumw = dcum;
+    const size_t ufstride = ids_max + 2 * ((ids_max + 31) / 32);
+    if ((rc = dalloc(b, &D.uf_scratch, (size_t)D.R * ufstride, false))) return fail(rc);
+    if ((rc = dalloc(b, &b->d_beta, D.R))) return fail(rc);
+    if ((rc = dalloc(b, &b->d_out, D.R))) return fail(rc);
+    if ((rc = dalloc(b, &b->d_vstate, (size_t)D.R * D.nwords))) return fail(rc);
+    if ((rc = dalloc(b, &b->d_ok, D.R))) return fail(rc);
+    if (hipMemcpy(dbonds, tab.data(), sizeof(BondRec) * D.Nb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dcum, cum.data(), sizeof(double) * D.Nb, hipMemcpyHostToDevice) != hipSuccess) { b->err = "table upload failed"; return fail(ISINGMC_ENODEVICE); }
+    std::vector<uint32_t> cut(D.R, cfg->cutoff0);
+    if (hipMemcpy(D.cutoff, cut.data(), sizeof(uint32_t) * D.R, hipMemcpyHostToDevice) != hipSuccess) { b->err = "cutoff upload failed"; return fail(ISINGMC_ENODEVICE); }
+    if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { b->err = "hipEventCreate failed"; return fail(ISINGMC_ENODEVICE); }
+
+    if (cfg->init_state) {
+        rc = isingmc_set_state(b, UINT32_MAX, cfg->init_state);
+        if (rc) return fail(rc);
+    } else {
+        hipLaunchKernelGGL(init_state_kernel, dim3(D.R), dim3(64), 0, b->stream, D);
+        if (hipDeviceSynchronize() != hipSuccess) { b->err = "init_state_kernel failed"; return fail(ISINGMC_ENODEVICE); }
+    }
+    *out = b;
+    return ISINGMC_OK;
+}
+
+void isingmc_destroy(isingmc_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    for (void *p : b->allocs) (void)hipFree(p);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    delete b;
+}
+
+const char *isingmc_last_error(const isingmc_batch *b) { return b ? b->err.c_str() : g_create_error.c_str(); }
+
+int isingmc_diagonal_update(isingmc_batch *b, const double *beta, uint32_t flags) {
+    uint32_t m = SSE_DO_DIAG | SSE_DO_GROW;
+    if (flags & ISINGMC_FLAG_HEATBATH) m |= SSE_DO_HEATBATH;
+    return run(b, beta, 1, 0, m, 0.5, nullptr);
+}
+int isingmc_cluster_update(isingmc_batch *b, double prob, uint32_t *n_clusters) {
+    if (b && !(prob >= 0.0 && prob <= 1.0)) { b->err = "prob must be in [0,1]"; return ISINGMC_EINVAL; }
+    std::vector<uint32_t> tmp;
+    if (b && !n_clusters) { tmp.resize(b->dev.R); n_clusters = tmp.data(); }
+    return run(b, nullptr, 1, 0, SSE_DO_CLUSTER, prob, n_clusters);
+}
+int isingmc_loop_update(isingmc_batch *b, uint32_t *lengths) {
+    std::vector<uint32_t> tmp;
+    if (b && !lengths) { tmp.resize(b->dev.R); lengths = tmp.data(); }
+    return run(b, nullptr, 1, 0, SSE_DO_LOOP, 0.5, lengths);
+}
+int isingmc_flip_free_spins(isingmc_batch *b) { return run(b, nullptr, 1, 0, SSE_DO_FREE, 0.5, nullptr); }
+
+int isingmc_timesteps(isingmc_batch *b, uint64_t t, const double *beta, uint32_t sampling_freq, uint32_t flags) {
+    if (!b) return ISINGMC_EINVAL;
+    if (flags & ISINGMC_FLAG_RVB) { b->err = "RVB updates are not implemented in this build"; return ISINGMC_ENOTIMPL; }
+    uint32_t m = SSE_DO_DIAG | SSE_DO_GROW | SSE_DO_FREE;
+    if (flags & ISINGMC_FLAG_HEATBATH) m |= SSE_DO_HEATBATH;
+    if (flags & ISINGMC_FLAG_LOOP) m |= SSE_DO_LOOP;
+    if (!(flags & ISINGMC_FLAG_NO_CLUSTER)) m |= SSE_DO_CLUSTER;
+    if (sampling_freq == 0) sampling_freq = 1; // qmc_stepper.rs:147 unwrap_or(1)
+    if (t == 0) return ISINGMC_OK;
+    return run(b, beta, t, sampling_freq, m, 0.5, nullptr);
+}
+
+int isingmc_get_accumulators(isingmc_batch *b, uint64_t *out) {
+    if (!b || !out) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipMemcpy(out, b->dev.acc, sizeof(uint64_t) * 8 * b->dev.R, hipMemcpyDeviceToHost));
+    return ISINGMC_OK;
+}
+int isingmc_reset_accumulators(isingmc_batch *b) {
+    if (!b) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipMemset(b->dev.acc, 0, sizeof(uint64_t) * 8 * b->dev.R));
+    return ISINGMC_OK;
+}
+double isingmc_get_offset(const isingmc_batch *b) { return b ? b->offset : 0.0; }
+uint32_t isingmc_num_bonds(const isingmc_batch *b) { return b ? b->dev.Nb : 0u; }
+
+int isingmc_get_state(isingmc_batch *b, uint32_t r, uint8_t *out) {
+    if (!b || !out || (r != UINT32_MAX && r >= b->dev.R)) { if (b) b->err = "bad replica index"; return ISINGMC_EINVAL; }
+    HIP_TRY(b, hipSetDevice(b->device));
+    const uint32_t r0 = r == UINT32_MAX ? 0 : r, cnt = r == UINT32_MAX ? b->dev.R : 1;
+    std::vector<uint32_t> w((size_t)cnt * b->dev.nwords);
+    HIP_TRY(b, hipMemcpy(w.data(), b->dev.state + (size_t)r0 * b->dev.nwords, w.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < cnt; ++i)
+        for (uint32_t v = 0; v < b->dev.N; ++v) out[(size_t)i * b->dev.N + v] = (w[(size_t)i * b->dev.nwords + (v >> 5)] >> (v & 31)) & 1u;
+    return ISINGMC_OK;
+}
+int isingmc_set_state(isingmc_batch *b, uint32_t r, const uint8_t *in) {
+    if (!b || !in || (r != UINT32_MAX && r >= b->dev.R)) { if (b) b->err = "bad replica index"; return ISINGMC_EINVAL; }
+    HIP_TRY(b, hipSetDevice(b->device));
+    const uint32_t r0 = r == UINT32_MAX ? 0 : r, cnt = r == UINT32_MAX ? b->dev.R : 1;
+    std::vector<uint32_t> w((size_t)cnt * b->dev.nwords, 0u);
+    for (uint32_t i = 0; i < cnt; ++i)
+        for (uint32_t v = 0; v < b->dev.N; ++v)
+            if (in[(size_t)i * b->dev.N + v]) w[(size_t)i * b->dev.nwords + (v >> 5)] |= 1u << (v & 31);
+    HIP_TRY(b, hipMemcpy(b->dev.state + (size_t)r0 * b->dev.nwords, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    return ISINGMC_OK;
+}
+
+static int get_u32(isingmc_batch *b, const uint32_t *src, uint32_t *out) {
+    if (!b || !out) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipMemcpy(out, src, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost));
+    return ISINGMC_OK;
+}
+int isingmc_get_n(isingmc_batch *b, uint32_t *out) { return b ? get_u32(b, b->dev.n, out) : ISINGMC_EINVAL; }
+int isingmc_get_cutoff(isingmc_batch *b, uint32_t *out) { return b ? get_u32(b, b->dev.cutoff, out) : ISINGMC_EINVAL; }
+int isingmc_get_epoch(isingmc_batch *b, uint64_t *out) {
+    if (!b || !out) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipMemcpy(out, b->dev.epoch, sizeof(uint64_t) * b->dev.R, hipMemcpyDeviceToHost));
+    return ISINGMC_OK;
+}
+int isingmc_set_cutoff(isingmc_batch *b, uint32_t r, uint32_t cutoff) {
+    if (!b || r >= b->dev.R) { if (b) b->err = "bad replica index"; return ISINGMC_EINVAL; }
+    if (cutoff > b->dev.cap) { b->err = "cutoff exceeds capacity"; return ISINGMC_ECAPACITY; }
+    HIP_TRY(b, hipSetDevice(b->device));
+    uint32_t cur = 0;
+    HIP_TRY(b, hipMemcpy(&cur, b->dev.cutoff + r, 4, hipMemcpyDeviceToHost));
+    if (cutoff > cur) HIP_TRY(b, hipMemcpy(b->dev.cutoff + r, &cutoff, 4, hipMemcpyHostToDevice)); // fast_ops.rs:1258-1262: only grows
+    return ISINGMC_OK;
+}
+
+int isingmc_export_ops(isingmc_batch *b, uint32_t r, uint32_t *words, uint32_t nwords) {
+    if (!b || !words || r >= b->dev.R || nwords > b->dev.cap) { if (b) b->err = "bad arguments to export_ops"; return ISINGMC_EINVAL; }
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipMemcpy(words, b->dev.ops + (size_t)r * b->dev.cap, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost));
+    return ISINGMC_OK;
+}
+int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint32_t nwords) {
+    if (!b || (!words && nwords) || r >= b->dev.R) { if (b) b->err = "bad arguments to import_ops"; return ISINGMC_EINVAL; }
+    if (nwords > b->dev.cap) { b->err = "op-string longer than capacity"; return ISINGMC_ECAPACITY; }
+    uint32_t n = 0, ntr = 0;
+    for (uint32_t p = 0; p < nwords; ++p) {
+        if (!words[p]) continue;
+        const uint32_t bond = sse_op_bond(words[p]);
+        if (bond >= b->dev.Nb) { b->err = "op refers to a bond outside the model"; return ISINGMC_EINVAL; }
+        n++;
+        if (((b->bonds_host[bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK) == SSE_BOND_TRANSVERSE) ntr++;
+    }
+    HIP_TRY(b, hipSetDevice(b->device));
+    uint32_t *dst = b->dev.ops + (size_t)r * b->dev.cap;
+    HIP_TRY(b, hipMemset(dst, 0, sizeof(uint32_t) * b->dev.cap));
+    if (nwords) HIP_TRY(b, hipMemcpy(dst, words, sizeof(uint32_t) * nwords, hipMemcpyHostToDevice));
+    uint32_t cur = 0;
+    HIP_TRY(b, hipMemcpy(&cur, b->dev.cutoff + r, 4, hipMemcpyDeviceToHost));
+    if (nwords > cur) HIP_TRY(b, hipMemcpy(b->dev.cutoff + r, &nwords, 4, hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(b->dev.n + r, &n, 4, hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(b->dev.ntrans + r, &ntr, 4, hipMemcpyHostToDevice));
+    return ISINGMC_OK;
+}
+int isingmc_get_bond_count(isingmc_batch *b, uint32_t r, uint32_t bond, uint32_t *out) {
+    if (!b || !out || r >= b->dev.R) { if (b) b->err = "bad arguments to get_bond_count"; return ISINGMC_EINVAL; }
+    std::vector<uint32_t> w(b->dev.cap);
+    int rc = isingmc_export_ops(b, r, w.data(), b->dev.cap);
+    if (rc) return rc;
+    uint32_t c = 0;
+    for (uint32_t x : w) if (x && sse_op_bond(x) == bond) c++;
+    *out = c;
+    return ISINGMC_OK;
+}
+
+int isingmc_verify(isingmc_batch *b, uint8_t *ok) {
+    if (!b || !ok) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    hipLaunchKernelGGL(verify_kernel, dim3((b->dev.R + 63) / 64), dim3(64), 0, b->stream, b->dev, b->d_vstate, b->d_ok);
+    HIP_TRY(b, hipGetLastError());
+    HIP_TRY(b, hipMemcpyAsync(ok, b->d_ok, b->dev.R, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    return ISINGMC_OK;
+}
+
+int isingmc_set_stream(isingmc_batch *b, void *hip_stream) {
+    if (!b) return ISINGMC_EINVAL;
+    b->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return ISINGMC_OK;
+}
+int isingmc_synchronize(isingmc_batch *b) {
+    if (!b) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    return ISINGMC_OK;
+}
+int isingmc_last_kernel_ms(isingmc_batch *b, float *ms, uint32_t *launches) {
+    if (!b) return ISINGMC_EINVAL;
+    if (ms) *ms = b->last_ms;
+    if (launches) *launches = b->last_launches;
+    return ISINGMC_OK;
+}
+int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[4]) {
+    if (!b || !out) return ISINGMC_EINVAL;
+    out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
+    return ISINGMC_OK;
+}
+
+} // extern "C"

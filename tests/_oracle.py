@@ -1,0 +1,189 @@
+"""ctypes binding of the CPU oracle (oracle/libsse_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = os.path.join(_ORACLE_DIR, "libsse_oracle.so")
+
+FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
+
+
+def load():
+    if not os.path.exists(_LIB):
+        build()
+    lib = C.CDLL(_LIB)
+    u32, u64, f64, vp = C.c_uint32, C.c_uint64, C.c_double, C.c_void_p
+    p = C.POINTER
+    sig = {
+        "ora_model_create": (vp, [u32, u32, p(u32), p(u32), p(f64), f64, f64]),
+        "ora_model_destroy": (None, [vp]),
+        "ora_model_nbonds": (u32, [vp]),
+        "ora_model_offset": (f64, [vp]),
+        "ora_replica_create": (vp, [vp, u32, u32, u64, u32, p(C.c_uint8)]),
+        "ora_replica_destroy": (None, [vp]),
+        "ora_diagonal_update": (None, [vp, f64]),
+        "ora_heatbath_update": (None, [vp, f64]),
+        "ora_cluster_update": (u32, [vp, f64]),
+        "ora_flip_free_spins": (None, [vp]),
+        "ora_loop_update": (u32, [vp]),
+        "ora_timestep": (C.c_int, [vp, f64, u32]),
+        "ora_timesteps": (C.c_int, [vp, u64, f64, u32, u32]),
+        "ora_verify": (C.c_int, [vp]),
+        "ora_get_n": (u32, [vp]),
+        "ora_get_cutoff": (u32, [vp]),
+        "ora_set_cutoff": (C.c_int, [vp, u32]),
+        "ora_get_epoch": (u64, [vp]),
+        "ora_get_state": (None, [vp, p(C.c_uint8)]),
+        "ora_set_state": (None, [vp, p(C.c_uint8)]),
+        "ora_get_ops": (None, [vp, p(u32)]),
+        "ora_set_ops": (C.c_int, [vp, p(u32), u32]),
+        "ora_get_bond_count": (u32, [vp, u32]),
+        "ora_get_accumulators": (None, [vp, p(u64)]),
+        "ora_reset_accumulators": (None, [vp]),
+        "ora_batch_timesteps": (C.c_int, [p(vp), u32, u64, p(f64), u32, u32, C.c_int]),
+        "ora_max_threads": (C.c_int, []),
+        "ora_philox4x32_10": (None, [p(u32), p(u32), p(u32)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+LIB = None
+
+
+def lib():
+    global LIB
+    if LIB is None:
+        LIB = load()
+    return LIB
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def op_make(bond, in_bits, out_bits):
+    return ((bond + 1) << 4) | (in_bits & 3) | ((out_bits & 3) << 2)
+
+
+class Model:
+    def __init__(self, nvars, edges, J, gamma, h=0.0):
+        self.nvars = int(nvars)
+        self.edges = np.ascontiguousarray(np.asarray(edges, dtype=np.uint32).reshape(-1, 2))
+        self.J = np.ascontiguousarray(np.asarray(J, dtype=np.float64))
+        self.gamma, self.h = float(gamma), float(h)
+        ea = np.ascontiguousarray(self.edges[:, 0])
+        eb = np.ascontiguousarray(self.edges[:, 1])
+        self.ptr = lib().ora_model_create(self.nvars, len(self.J), _ptr(ea, C.c_uint32), _ptr(eb, C.c_uint32),
+                                          _ptr(self.J, C.c_double), self.gamma, self.h)
+        self.nbonds = lib().ora_model_nbonds(self.ptr)
+        self.offset = lib().ora_model_offset(self.ptr)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().ora_model_destroy(self.ptr)
+            self.ptr = None
+
+
+class Replica:
+    def __init__(self, model, capacity, cutoff0, seed, replica=0, init_state=None):
+        self.model = model
+        st = None
+        if init_state is not None:
+            arr = np.ascontiguousarray(np.asarray(init_state, dtype=np.uint8))
+            st = _ptr(arr, C.c_uint8)
+        self.ptr = lib().ora_replica_create(model.ptr, capacity, cutoff0, seed, replica, st)
+        assert self.ptr, "oracle replica creation failed"
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().ora_replica_destroy(self.ptr)
+            self.ptr = None
+
+    def diagonal_update(self, beta):
+        lib().ora_diagonal_update(self.ptr, beta)
+
+    def heatbath_update(self, beta):
+        lib().ora_heatbath_update(self.ptr, beta)
+
+    def cluster_update(self, prob=0.5):
+        return lib().ora_cluster_update(self.ptr, prob)
+
+    def flip_free_spins(self):
+        lib().ora_flip_free_spins(self.ptr)
+
+    def loop_update(self):
+        return lib().ora_loop_update(self.ptr)
+
+    def timestep(self, beta, flags=0):
+        return lib().ora_timestep(self.ptr, beta, flags)
+
+    def timesteps(self, t, beta, freq=1, flags=0):
+        rc = lib().ora_timesteps(self.ptr, t, beta, freq, flags)
+        assert rc == 0, "oracle: cutoff exceeded capacity"
+
+    def verify(self):
+        return bool(lib().ora_verify(self.ptr))
+
+    @property
+    def n(self):
+        return lib().ora_get_n(self.ptr)
+
+    @property
+    def cutoff(self):
+        return lib().ora_get_cutoff(self.ptr)
+
+    def set_cutoff(self, c):
+        return lib().ora_set_cutoff(self.ptr, c)
+
+    @property
+    def epoch(self):
+        return lib().ora_get_epoch(self.ptr)
+
+    def state(self):
+        out = np.zeros(self.model.nvars, dtype=np.uint8)
+        lib().ora_get_state(self.ptr, _ptr(out, C.c_uint8))
+        return out
+
+    def set_state(self, s):
+        arr = np.ascontiguousarray(np.asarray(s, dtype=np.uint8))
+        lib().ora_set_state(self.ptr, _ptr(arr, C.c_uint8))
+
+    def ops(self):
+        out = np.zeros(self.cutoff, dtype=np.uint32)
+        lib().ora_get_ops(self.ptr, _ptr(out, C.c_uint32))
+        return out
+
+    def set_ops(self, words):
+        arr = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
+        rc = lib().ora_set_ops(self.ptr, _ptr(arr, C.c_uint32), len(arr))
+        assert rc == 0
+
+    def bond_count(self, b):
+        return lib().ora_get_bond_count(self.ptr, b)
+
+    def accumulators(self):
+        out = np.zeros(8, dtype=np.uint64)
+        lib().ora_get_accumulators(self.ptr, _ptr(out, C.c_uint64))
+        return out
+
+    def reset_accumulators(self):
+        lib().ora_reset_accumulators(self.ptr)
+
+
+def batch_timesteps(replicas, t, betas, freq=1, flags=0, nthreads=0):
+    arr = (C.c_void_p * len(replicas))(*[r.ptr for r in replicas])
+    b = np.ascontiguousarray(np.asarray(betas, dtype=np.float64))
+    rc = lib().ora_batch_timesteps(arr, len(replicas), t, _ptr(b, C.c_double), freq, flags, nthreads)
+    assert rc == 0
