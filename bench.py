@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the SSE sweep on MI355X (BASELINE.json metric).
+
+A "step" is one SSE sweep (timestep) of every replica resident on a GPU.  Workload = BASELINE.json
+configs[1]: 32x32 periodic square-lattice TFIM, J=-1 (ferromagnet in the reference's sign convention),
+Gamma=1, h=0, beta=16, 1024 independent replicas per GPU, driven like the reference's Qmc::timestep with
+loop updates enabled (src/sse/qmc_runner.rs:363-377): diagonal sweep -> one directed loop -> cluster
+flips -> free-spin randomisation.  Synthetic input = op-strings equilibrated on the device before the
+warm-up (the cutoff must first grow from N to ~1.5 n; that growth is data preparation, not the workload).
+
+value = spin-operator updates / second, whole job: one update = one op-string slot processed by one pass
+(diagonal pass: cutoff M slots; off-diagonal passes: vertices visited), summed over all ranks' replicas.
+
+Multi-GPU: replicas shard across ranks (weak scaling: 1024 replicas per GPU), no data-path collective;
+launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# algorithmic HBM bytes per slot per sweep with one u32 word per slot:
+#   diagonal pass 4 B read + 4 B written; cluster pass build 4 B read + apply 4 B read + 4 B written;
+#   directed loop start search 4 B read.
+BYTES_PER_SLOT_DIAG, BYTES_PER_SLOT_CLUSTER, BYTES_PER_SLOT_LOOP = 8.0, 12.0, 4.0
+
+
+def lattice_edges(l):
+    import _lattices as lat
+    return lat.two_d_ferro(l)
+
+
+def cpu_baseline(l, beta, flags, seed, budget_s=20.0):
+    """Time the CPU oracle (a C restatement of the reference path, kind='port') on this box's host cores."""
+    import _oracle
+    import _lattices as lat
+    _oracle.build()
+    edges = lattice_edges(l)
+    e, j = lat.split(edges)
+    nthreads = max(1, min(_oracle.lib().ora_max_threads(), os.cpu_count() or 1))
+    m = _oracle.Model(l * l, e, j, 1.0, 0.0)
+    reps = [_oracle.Replica(m, 1 << 18, l * l, seed, 1_000_000 + r) for r in range(nthreads)]
+    betas = [beta] * nthreads
+    t0 = time.time()
+    _oracle.batch_timesteps(reps, 60, betas, 1, flags, nthreads)  # equilibrate (untimed)
+    t_eq = time.time() - t0
+    per_sweep = max(t_eq / 60.0, 1e-4)
+    sweeps = int(max(4, min(200, (budget_s - t_eq) / per_sweep))) if budget_s > t_eq else 4
+    for r in reps:
+        r.reset_accumulators()
+    t0 = time.time()
+    _oracle.batch_timesteps(reps, sweeps, betas, 1, flags, nthreads)
+    dt = time.time() - t0
+    upd = sum(int(r.accumulators()[4]) + int(r.accumulators()[5]) for r in reps)
+    return {"value": upd / dt, "unit": "spin-op updates/s", "cores": nthreads, "kind": "port",
+            "sample": f"{nthreads} replicas (one per thread) x {sweeps} sweeps of the same {l}x{l} beta={beta} "
+                      f"workload after 60 equilibration sweeps; C oracle, not the Rust binary",
+            "sweeps_per_s_per_core": sweeps / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
+    ap.add_argument("--L", type=int, default=32)
+    ap.add_argument("--beta", type=float, default=16.0)
+    ap.add_argument("--equilibrate", type=int, default=80, help="untimed sweeps that prepare the synthetic input")
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--no-loop", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import isingmontecarlo_amd as im
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    flags = 0 if args.no_loop else im.FLAG_LOOP
+    L, R, beta = args.L, args.replicas, args.beta
+    edges = lattice_edges(L)
+    n_est = beta * (3 * L * L + 2.2 * L * L)
+    cap = 1 << int(np.ceil(np.log2(2.0 * n_est + 4 * L * L)))
+    g = im.QmcIsingGraph(edges, 1.0, 0.0, L * L, args.seed, nreplicas=R, capacity=cap,
+                         replica_offset=rank * R, device=local_rank, waves_per_replica=args.waves)
+    # data preparation: equilibrate (cutoff growth + thermalisation), untimed
+    g.run(args.equilibrate, beta, flags=flags)
+    # warm-up
+    if args.warmup:
+        g.run(args.warmup, beta, flags=flags)
+    g.reset_accumulators()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.run(args.steps, beta, flags=flags)  # EXACTLY K steps, one fused launch, returns after completion
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    acc = g.accumulators().astype(np.float64)
+    updates = float(acc[:, 4].sum() + acc[:, 5].sum())
+    slots = float(acc[:, 5].sum())  # sum over replicas and steps of the cutoff M
+    kernel_ms, launches = g.last_kernel_ms()
+    mean_M = slots / (R * args.steps)
+    mean_n = float(acc[:, 0].sum() / max(1.0, acc[:, 1].sum()))
+    t = torch.tensor([dt, updates, slots, kernel_ms], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, updates, slots_all = float(tmax[0]), float(tsum[1]), float(tsum[2])
+    else:
+        slots_all = slots
+
+    if rank == 0:
+        bytes_per_slot = BYTES_PER_SLOT_DIAG + BYTES_PER_SLOT_CLUSTER + (0.0 if args.no_loop else BYTES_PER_SLOT_LOOP)
+        alg_bytes_launch = bytes_per_slot * slots  # rank 0's launch: K sweeps of R replicas
+        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        energy = -(acc[:, 0] / np.maximum(acc[:, 1], 1)) / beta + g.get_offset()
+        out = {
+            "metric": "spin-op updates/sec (whole node), 32x32 TFIM, 1024 replicas per GPU",
+            "value": updates / dt,
+            "unit": "spin-op updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 op words, f64 acceptance arithmetic",
+            "data": "synthetic (op-strings equilibrated on device from random spins, Philox seed %d)" % args.seed,
+            "config": {"workload": f"configs[1]: {L}x{L} periodic TFIM J=-1 Gamma=1 h=0 beta={beta}, {R} replicas/GPU, "
+                                   f"Qmc::timestep = diagonal + {'directed loop + ' if not args.no_loop else ''}cluster + free spins",
+                       "replicas_per_gpu": R, "lattice": f"{L}x{L}", "beta": beta,
+                       "mean_cutoff_M": mean_M, "mean_n": mean_n, "sweeps_per_s": args.steps / dt,
+                       "waves_per_replica": g.launch_info()["waves_per_replica"],
+                       "energy_per_site": float(energy.mean() / (L * L)),
+                       "energy_per_site_sem": float(energy.std(ddof=1) / np.sqrt(R) / (L * L)) if R > 1 else None},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sse::sweep_kernel", "kernel_ms_per_launch": kernel_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch, "bytes_per_slot": bytes_per_slot},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L, beta, flags, args.seed)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

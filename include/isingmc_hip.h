@@ -37,6 +37,11 @@ extern "C" {
 #define ISINGMC_FLAG_NO_CLUSTER 2u /* skip the cluster step */
 #define ISINGMC_FLAG_HEATBATH 4u   /* set_enable_heatbath(true) (qmc_ising.rs:444) / set_do_heatbath (qmc_runner.rs:258) */
 #define ISINGMC_FLAG_RVB 8u        /* set_run_rvb(true) (qmc_ising.rs:435) */
+#define ISINGMC_FLAG_PREP 0x10000u /* profiling label only: run the identical kernel under its "data preparation"
+                                      symbol so that profilers separate input generation from the measured sweeps */
+
+/* isingmc_config.flags */
+#define ISINGMC_CFG_NO_LDS_TABLES 1u /* keep the bond table in HBM even when it would fit in LDS (testing) */
 
 typedef struct isingmc_batch isingmc_batch;
 
@@ -55,8 +60,11 @@ typedef struct isingmc_config {
     uint32_t replica_offset;  /* global index of local replica 0 (replica sharding over GPUs) */
     int32_t device;           /* HIP device ordinal, -1 = current device */
     const uint8_t *init_state; /* [R][N] 0/1 or NULL = random (make_random_spin_state, classical/graph.rs:451) */
-    uint32_t waves_per_replica; /* 0 = auto; workgroup = this many wave64s cooperating on one replica */
-    uint32_t reserved;
+    uint32_t waves_per_replica; /* 0 = auto (8); workgroup = this many wave64s cooperating on one replica: 1,4,8,16 */
+    uint32_t slots_per_lane;    /* 0 = auto (4); op-string slots each lane holds per tile: 1,2,4 */
+    uint32_t flags;             /* ISINGMC_CFG_* */
+    uint32_t lds_uf_ids_limit;  /* 0 = as many cluster-segment ids as fit in LDS; smaller values force the HBM
+                                   union-find path earlier (testing) */
 } isingmc_config;
 
 /* QmcIsingGraph::new_with_rng (qmc_ising.rs:131-148) + OpContainerConstructor::new_with_bonds
@@ -116,9 +124,12 @@ int isingmc_set_stream(isingmc_batch *b, void *hip_stream);
 int isingmc_synchronize(isingmc_batch *b);
 /* HIP-event timing of the most recent isingmc_timesteps launch(es): total ms and number of kernel launches */
 int isingmc_last_kernel_ms(isingmc_batch *b, float *ms, uint32_t *launches);
+/* number of sweeps fused into one kernel launch by isingmc_timesteps (0 = all t steps in one launch) */
+int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
 /* build/launch configuration actually in use: out[0]=waves per replica, out[1]=dynamic LDS bytes,
- * out[2]=union-find ids that fit in LDS, out[3]=state words per replica */
-int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[4]);
+ * out[2]=union-find ids that fit in LDS, out[3]=state words per replica, out[4]=slots per lane,
+ * out[5]=1 if the edge table is staged in LDS, out[6..7] reserved */
+int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -69,8 +69,11 @@ SSE_HD static inline int sse_op_is_diagonal(uint32_t w) { return sse_op_in(w) ==
 /* ---- Philox4x32-10 counter assignment ------------------------------------------------
  *   key     = (seed_lo, seed_hi)
  *   counter = (index, epoch_lo, replica, (tag << 24) | (epoch_hi & 0xFFFFFF))
- * index is the op-string slot p (diagonal pass), the canonical cluster label (cluster coin),
- * the variable (free spins / initial state) or the step number (directed loop).
+ * index is the op-string slot p (heat-bath diagonal pass), the slot pair (Metropolis diagonal pass, see
+ * below), the canonical cluster label (cluster coin), the variable (free spins / initial state) or the
+ * step number (directed loop).
+ * Metropolis diagonal pass: slots p and p^64 share one call with index = p & ~64; the slot with bit 6
+ * clear uses words (0: bond choice, 1: accept), the other words (2: bond choice, 3: accept).
  * Every primitive update consumes one epoch value and increments the replica's epoch.
  */
 #define SSE_TAG_INIT 0u

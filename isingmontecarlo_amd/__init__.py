@@ -13,9 +13,11 @@ import numpy as np
 from . import _build
 
 __all__ = ["QmcIsingGraph", "Qmc", "IsingMcError", "load_library", "op_make", "op_fields",
-           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB"]
+           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES"]
 
 FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
+FLAG_PREP = 0x10000
+CFG_NO_LDS_TABLES = 1
 ALL = 0xFFFFFFFF
 
 _ERRNAMES = {-1: "EINVAL", -2: "ENODEVICE", -3: "ECAPACITY", -4: "EINTEGRITY", -5: "ENOTIMPL"}
@@ -33,7 +35,8 @@ class _Config(C.Structure):
                 ("transverse", C.c_double), ("longitudinal", C.c_double), ("capacity", C.c_uint32),
                 ("cutoff0", C.c_uint32), ("seed", C.c_uint64), ("replica_offset", C.c_uint32),
                 ("device", C.c_int32), ("init_state", C.POINTER(C.c_uint8)),
-                ("waves_per_replica", C.c_uint32), ("reserved", C.c_uint32)]
+                ("waves_per_replica", C.c_uint32), ("slots_per_lane", C.c_uint32), ("flags", C.c_uint32),
+                ("lds_uf_ids_limit", C.c_uint32)]
 
 
 # every symbol include/isingmc_hip.h declares: name -> (restype, argtypes)
@@ -63,6 +66,7 @@ SYMBOLS = {
     "isingmc_import_ops": (C.c_int, [_vp, _u32, _P(_u32), _u32]),
     "isingmc_verify": (C.c_int, [_vp, _P(C.c_uint8)]),
     "isingmc_set_stream": (C.c_int, [_vp, _vp]),
+    "isingmc_set_steps_per_launch": (C.c_int, [_vp, _u64]),
     "isingmc_synchronize": (C.c_int, [_vp]),
     "isingmc_last_kernel_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
     "isingmc_get_launch_info": (C.c_int, [_vp, _P(_u32)]),
@@ -114,7 +118,8 @@ class QmcIsingGraph:
     """
 
     def __init__(self, edges, transverse, longitudinal, cutoff, seed, state=None, nreplicas=1,
-                 capacity=None, replica_offset=0, device=-1, waves_per_replica=0):
+                 capacity=None, replica_offset=0, device=-1, waves_per_replica=0, slots_per_lane=0,
+                 cfg_flags=0, lds_uf_ids_limit=0):
         lib = load_library()
         self._lib = lib
         self._h = None
@@ -141,7 +146,8 @@ class QmcIsingGraph:
                       longitudinal=self.longitudinal, capacity=int(capacity), cutoff0=int(cutoff), seed=int(seed),
                       replica_offset=int(replica_offset), device=int(device),
                       init_state=_ptr(init, C.c_uint8) if init is not None else None,
-                      waves_per_replica=int(waves_per_replica), reserved=0)
+                      waves_per_replica=int(waves_per_replica), slots_per_lane=int(slots_per_lane),
+                      flags=int(cfg_flags), lds_uf_ids_limit=int(lds_uf_ids_limit))
         h = C.c_void_p()
         rc = lib.isingmc_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -301,9 +307,13 @@ class QmcIsingGraph:
         return ms.value, n.value
 
     def launch_info(self):
-        out = (C.c_uint32 * 4)()
+        out = (C.c_uint32 * 8)()
         self._check(self._lib.isingmc_get_launch_info(self._h, out))
-        return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3])
+        return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3],
+                    slots_per_lane=out[4], lds_edge_table=bool(out[5]))
+
+    def set_steps_per_launch(self, steps):
+        self._check(self._lib.isingmc_set_steps_per_launch(self._h, int(steps)))
 
     def into_qmc(self, do_loop_updates=False):
         """IntoQmc::into_qmc (qmc_ising.rs:943-976): same container driven through Qmc::timestep."""

@@ -16,7 +16,8 @@ static thread_local std::string g_create_error;
 
 struct isingmc_batch {
     DevBatch dev{};
-    uint32_t W = 8;
+    uint32_t W = 8, K = 4, CL = 0;
+    uint64_t steps_per_launch = 0;
     size_t lds_bytes = 0;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -64,17 +65,48 @@ __global__ void init_state_kernel(DevBatch B) {
     }
 }
 
-static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords) {
-    return (size_t)nwords * (W + 2) + 4 * W + 16 + (size_t)W * N;
+
+// Verify::verify (qmc_ising.rs:829-860; op_container.rs:137-159), one thread per replica (debug API, not on
+// the hot path).  ok[r] = 1 iff every op has non-zero weight, the propagated state matches every op's
+// inputs, periodicity holds, no op sits beyond the cutoff and the counters n / ntrans match the op-string.
+__global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*/, uint8_t *ok) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B.R) return;
+    uint32_t *s = scratch_state + (size_t)r * B.nwords;
+    const uint32_t *s0 = B.state + (size_t)r * B.nwords;
+    for (uint32_t i = 0; i < B.nwords; ++i) s[i] = s0[i];
+    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    const uint32_t M = B.cutoff[r];
+    bool good = true;
+    uint32_t count = 0, ntr = 0;
+    for (uint32_t p = 0; p < B.cap; ++p) {
+        const uint32_t w = ops[p];
+        if (!w) continue;
+        if (p >= M) { good = false; break; }
+        count++;
+        const uint32_t b = sse_op_bond(w);
+        if (b >= B.Nb) { good = false; break; }
+        const BondRec rec = B.bonds[b];
+        Bd d;
+        d.a = rec.a_info & SSE_VAR_MASK; d.c = rec.c; d.kp = rec.a_info >> SSE_INFO_SHIFT; d.w = rec.w;
+        const uint32_t in = sse_op_in(w), out = sse_op_out(w);
+        if (!(bond_weight(d, in, out) > 2.220446049250313e-16)) good = false;
+        if (bd_kind(d) == SSE_BOND_TRANSVERSE) ntr++;
+        const uint32_t a = d.a, c = d.c;
+        if (((s[a >> 5] >> (a & 31)) & 1u) != (in & 1u)) good = false;
+        s[a >> 5] = (s[a >> 5] & ~(1u << (a & 31))) | ((out & 1u) << (a & 31));
+        if (c != SSE_NO_VAR) {
+            if (((s[c >> 5] >> (c & 31)) & 1u) != ((in >> 1) & 1u)) good = false;
+            s[c >> 5] = (s[c >> 5] & ~(1u << (c & 31))) | (((out >> 1) & 1u) << (c & 31));
+        } else if ((in | out) & 2u) good = false;
+    }
+    for (uint32_t i = 0; i < B.nwords; ++i) if (s[i] != s0[i]) good = false;
+    if (count != B.n[r] || ntr != B.ntrans[r]) good = false;
+    ok[r] = good ? 1 : 0;
 }
 
-template <int W>
-static hipError_t launch_sweep(isingmc_batch *b, const SweepArgs &A) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel<W>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sweep_kernel<W>, dim3(b->dev.R), dim3(W * 64), b->lds_bytes, b->stream, b->dev, A);
-    return hipGetLastError();
+static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges) {
+    return (size_t)nwords * (W + 2) + 4 * W + 16 + ledges + (size_t)W * N;
 }
 
 static int check_errors(isingmc_batch *b) {
@@ -111,26 +143,33 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         b->err = "beta is required for a diagonal update";
         return ISINGMC_EINVAL;
     }
-    A.nsteps = nsteps;
     A.sampling_freq = freq;
-    A.domask = domask;
+    A.domask = domask & 0xFFFFu;
     A.prob = prob;
     A.out_u32 = out_host ? b->d_out : nullptr;
+    LaunchCfg lc{};
+    lc.W = b->W; lc.K = b->K; lc.CL = b->CL; lc.phase = (domask >> 16) & 1u; lc.lds_bytes = b->lds_bytes; lc.stream = b->stream;
+    const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;
+    uint32_t launches = 0;
     HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
-    hipError_t e;
-    switch (b->W) {
-    case 1: e = launch_sweep<1>(b, A); break;
-    case 2: e = launch_sweep<2>(b, A); break;
-    case 4: e = launch_sweep<4>(b, A); break;
-    case 8: e = launch_sweep<8>(b, A); break;
-    case 16: e = launch_sweep<16>(b, A); break;
-    default: b->err = "unsupported waves_per_replica"; return ISINGMC_EINVAL;
+    for (uint64_t done = 0; done < nsteps; done += per) {
+        A.step0 = done;
+        A.nsteps = (nsteps - done < per) ? nsteps - done : per;
+        hipError_t e;
+        switch (b->W) {
+        case 1: e = launch_sweep_w1(lc, b->dev, A); break;
+        case 4: e = launch_sweep_w4(lc, b->dev, A); break;
+        case 8: e = launch_sweep_w8(lc, b->dev, A); break;
+        case 16: e = launch_sweep_w16(lc, b->dev, A); break;
+        default: b->err = "unsupported waves_per_replica"; return ISINGMC_EINVAL;
+        }
+        if (e != hipSuccess) { b->err = std::string("sweep launch: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; }
+        launches++;
     }
-    if (e != hipSuccess) { b->err = std::string("sweep launch: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; }
     HIP_TRY(b, hipEventRecord(b->ev1, b->stream));
     int rc = check_errors(b);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) { b->last_ms = ms; b->last_launches = 1; }
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) { b->last_ms = ms; b->last_launches = launches; }
     if (rc) return rc;
     if (out_host) HIP_TRY(b, hipMemcpy(out_host, b->d_out, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost));
     return ISINGMC_OK;
@@ -200,17 +239,27 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || max_lds <= 0) max_lds = 65536;
     const size_t total_words = (size_t)max_lds / 4;
     uint32_t W = cfg->waves_per_replica ? cfg->waves_per_replica : 8;
-    if (W != 1 && W != 2 && W != 4 && W != 8 && W != 16) { b->err = "waves_per_replica must be 1,2,4,8 or 16"; return fail(ISINGMC_EINVAL); }
-    while (W > 1 && lds_fixed_words(W, D.N, D.nwords) + 4096 > total_words) W >>= 1;
-    const size_t fixed = lds_fixed_words(W, D.N, D.nwords);
+    uint32_t K = cfg->slots_per_lane ? cfg->slots_per_lane : 4;
+    if (W != 1 && W != 4 && W != 8 && W != 16) { b->err = "waves_per_replica must be 1, 4, 8 or 16"; return fail(ISINGMC_EINVAL); }
+    if (K != 1 && K != 2 && K != 4) { b->err = "slots_per_lane must be 1, 2 or 4"; return fail(ISINGMC_EINVAL); }
+    // compact edge table staged in LDS when it is small enough (a|c<<15|pref<<30 needs N <= 32768)
+    const bool CL = D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
+    const uint32_t ledges = CL ? D.E : 0u;
+    while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : W >> 1;
+    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges);
     if (fixed + 64 > total_words) { b->err = "model too large: per-variable scan tables do not fit in LDS"; return fail(ISINGMC_ENOTIMPL); }
     const size_t remaining = total_words - fixed;
     size_t ufcap = (remaining - 2) * 32 / 34;
     const size_t ids_max = (size_t)D.N + D.cap;
     if (ufcap > ids_max) ufcap = ids_max;
+    if (cfg->lds_uf_ids_limit && ufcap > cfg->lds_uf_ids_limit) ufcap = cfg->lds_uf_ids_limit;
     D.lds_ufcap = (uint32_t)ufcap;
-    b->W = W;
+    b->W = W; b->K = K; b->CL = CL ? 1u : 0u;
     b->lds_bytes = 4 * (fixed + ufcap + 2 * ((ufcap + 31) / 32));
+    // uniform |J| lets the kernels keep the two-site weight in a scalar register
+    D.uniformJ = 1u; D.wJ = tab[0].w;
+    for (uint32_t e = 1; e < D.E; ++e) if (tab[e].w != tab[0].w) { D.uniformJ = 0u; break; }
+    D.gamma = cfg->transverse; D.wh = 2.0 * std::fabs(cfg->longitudinal); D.hpos = cfg->longitudinal > 0.0 ? 1u : 0u;
 
     int rc;
     if ((rc = dalloc(b, &D.ops, (size_t)D.R * D.cap))) return fail(rc);
@@ -226,6 +275,21 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if ((rc = dalloc(b, &dbonds, D.Nb, false))) return fail(rc);
     if ((rc = dalloc(b, &dcum, D.Nb, false))) return fail(rc);
     D.bonds = dbonds; D.cumw = dcum;
+    {
+        std::vector<double> ew(D.E);
+        std::vector<uint32_t> ce(D.E, 0u);
+        for (uint32_t e = 0; e < D.E; ++e) {
+            ew[e] = tab[e].w;
+            if (D.N <= SSE_CE_MAX_VARS)
+                ce[e] = (tab[e].a_info & SSE_CE_VAR_MASK) | ((tab[e].c & SSE_CE_VAR_MASK) << 15) | (((tab[e].a_info >> (SSE_INFO_SHIFT + 2)) & 1u) << 30);
+        }
+        double *dew = nullptr; uint32_t *dce = nullptr;
+        if ((rc = dalloc(b, &dew, D.E, false))) return fail(rc);
+        if ((rc = dalloc(b, &dce, D.E, false))) return fail(rc);
+        if (hipMemcpy(dew, ew.data(), sizeof(double) * D.E, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dce, ce.data(), sizeof(uint32_t) * D.E, hipMemcpyHostToDevice) != hipSuccess) { b->err = "edge table upload failed"; return fail(ISINGMC_ENODEVICE); }
+        D.edge_w = dew; D.edges_compact = dce;
+    }
     const size_t ufstride = ids_max + 2 * ((ids_max + 31) / 32);
     if ((rc = dalloc(b, &D.uf_scratch, (size_t)D.R * ufstride, false))) return fail(rc);
     if ((rc = dalloc(b, &b->d_beta, D.R))) return fail(rc);
@@ -285,6 +349,7 @@ int isingmc_timesteps(isingmc_batch *b, uint64_t t, const double *beta, uint32_t
     if (flags & ISINGMC_FLAG_HEATBATH) m |= SSE_DO_HEATBATH;
     if (flags & ISINGMC_FLAG_LOOP) m |= SSE_DO_LOOP;
     if (!(flags & ISINGMC_FLAG_NO_CLUSTER)) m |= SSE_DO_CLUSTER;
+    if (flags & ISINGMC_FLAG_PREP) m |= 0x10000u;
     if (sampling_freq == 0) sampling_freq = 1; // qmc_stepper.rs:147 unwrap_or(1)
     if (t == 0) return ISINGMC_OK;
     return run(b, beta, t, sampling_freq, m, 0.5, nullptr);
@@ -405,6 +470,11 @@ int isingmc_set_stream(isingmc_batch *b, void *hip_stream) {
     b->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return ISINGMC_OK;
 }
+int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps) {
+    if (!b) return ISINGMC_EINVAL;
+    b->steps_per_launch = steps;
+    return ISINGMC_OK;
+}
 int isingmc_synchronize(isingmc_batch *b) {
     if (!b) return ISINGMC_EINVAL;
     HIP_TRY(b, hipSetDevice(b->device));
@@ -417,9 +487,10 @@ int isingmc_last_kernel_ms(isingmc_batch *b, float *ms, uint32_t *launches) {
     if (launches) *launches = b->last_launches;
     return ISINGMC_OK;
 }
-int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[4]) {
+int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
+    out[4] = b->K; out[5] = b->CL;
     return ISINGMC_OK;
 }
 

@@ -1,12 +1,15 @@
 // sse_device.hip.h — gfx950 device code of the SSE sweep (workgroup-per-replica design).
 //
 // One workgroup of W wave64s owns one replica for a whole launch.  The op-string (one u32 per slot,
-// include/sse_format.h) streams from HBM in block-tiles of W*64 consecutive slots; everything that
-// the reference keeps in per-node linked lists (src/sse/fast_ops.rs:181-190: prev/next p, per-variable
-// prev/next) is recomputed on chip by ORDERED SCANS:
-//   * in-wave: wave64 ballot + a serial loop over the (few) writer lanes with v_readlane;
-//   * across the W waves of a tile: W copies of the per-variable table in LDS; a writer in wave w
-//     updates the copies of waves > w before the readers run and the copies of waves <= w after
+// include/sse_format.h) streams from HBM in tiles of W*64*K consecutive slots: wave w owns the contiguous
+// range [w*64K, (w+1)*64K) of the tile and walks it in K sub-rounds of 64 slots (lane l, sub-round j holds
+// slot w*64K + j*64 + l), so K coalesced 256-B loads per wave are in flight per tile.
+// Everything the reference keeps in per-node linked lists (src/sse/fast_ops.rs:181-190: prev/next p,
+// per-variable prev/next) is recomputed on chip by ORDERED SCANS:
+//   * inside a sub-round: wave64 ballot + a serial loop over the (few) writer lanes with v_readlane;
+//   * between sub-rounds of a wave: the wave updates its own copy of the per-variable table in LDS;
+//   * across the W waves of a tile: W copies of the table; a writer in wave w updates the copies of waves
+//     > w before the tile's readers run (one barrier) and the copies of waves < w after they are done
 //     (XOR for spin bits, MAX for monotonically increasing segment ids), so copy[w] always equals
 //     "the table as of the first slot of wave w in the current tile".
 // The live operator count n (the reference reads s.get_n() per slot, qmc_traits/diagonal.rs:126) makes
@@ -19,13 +22,16 @@
 
 namespace sse {
 
-struct BondRec {       // 16 B, one dwordx4 load
+struct BondRec {       // 16 B, one dwordx4 load (general table, any N / E)
     uint32_t a_info;   // var a | (kind|pref) << 29
     uint32_t c;        // second var or SSE_NO_VAR
     double w;          // weight when satisfied: 2|J|, Gamma, 2|h|
 };
 #define SSE_INFO_SHIFT 29
 #define SSE_VAR_MASK 0x1FFFFFFFu
+// compact edge entry (staged in LDS when N <= 32768): a | c << 15 | prefers_aligned << 30
+#define SSE_CE_VAR_MASK 0x7FFFu
+#define SSE_CE_MAX_VARS 32768u
 
 struct DevBatch {
     uint32_t R, N, E, Nb, cap, nwords;
@@ -35,9 +41,13 @@ struct DevBatch {
     uint64_t *epoch;      // [R]
     uint64_t *acc;        // [R][8]
     const BondRec *bonds; // [Nb]
+    const uint32_t *edges_compact; // [E] or null
+    const double *edge_w; // [E] 2|J|
     const double *cumw;   // [Nb] heat-bath cumulative weights
     double wtot;
-    uint32_t *uf_scratch; // [R][N+cap] union-find fallback in HBM
+    double wJ, gamma, wh; // uniform 2|J| (if uniformJ), Gamma, 2|h|
+    uint32_t uniformJ, hpos;
+    uint32_t *uf_scratch; // [R][N+cap (+bit arrays)] union-find fallback in HBM
     uint32_t seed_lo, seed_hi, replica_offset;
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
 };
@@ -53,6 +63,7 @@ struct DevBatch {
 struct SweepArgs {
     const double *beta; // [R]
     uint64_t nsteps;
+    uint64_t step0;     // index of the first step of this launch within the caller's timesteps() call
     uint32_t sampling_freq; // 0 = never sample
     uint32_t domask;
     double prob;
@@ -87,26 +98,21 @@ __device__ __forceinline__ Rng make_rng(const DevBatch &B, uint32_t r, uint64_t 
 }
 __device__ __forceinline__ double u01(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
 
-__device__ __forceinline__ uint32_t rec_var(const BondRec &b) { return b.a_info & SSE_VAR_MASK; }
-__device__ __forceinline__ uint32_t rec_kind(const BondRec &b) { return (b.a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK; }
-__device__ __forceinline__ uint32_t rec_pref(const BondRec &b) { return (b.a_info >> (SSE_INFO_SHIFT + 2)) & 1u; }
+// decoded bond: variables, kind|pref<<2, weight when satisfied
+struct Bd {
+    uint32_t a, c, kp;
+    double w;
+};
+__device__ __forceinline__ uint32_t bd_kind(const Bd &b) { return b.kp & SSE_BOND_KIND_MASK; }
 
 // matrix element of the shifted bond operator (reference: src/sse/qmc_ising.rs:863-888)
-__device__ __forceinline__ double bond_weight(const BondRec &b, uint32_t in, uint32_t out) {
-    const uint32_t kind = rec_kind(b), pref = rec_pref(b);
+__device__ __forceinline__ double bond_weight(const Bd &b, uint32_t in, uint32_t out) {
+    const uint32_t kind = b.kp & SSE_BOND_KIND_MASK, pref = (b.kp >> 2) & 1u;
     if (kind == SSE_BOND_TRANSVERSE) return b.w;
     if (in != out) return 0.0;
-    uint32_t sat = (kind == SSE_BOND_TWO_SITE) ? (uint32_t)(((in & 1u) == ((in >> 1) & 1u)) == (pref != 0u))
-                                               : (uint32_t)((in & 1u) == pref);
+    const uint32_t sat = (kind == SSE_BOND_TWO_SITE) ? (uint32_t)(((in & 1u) == ((in >> 1) & 1u)) == (pref != 0u))
+                                                     : (uint32_t)((in & 1u) == pref);
     return sat ? b.w : 0.0;
-}
-
-__device__ __forceinline__ BondRec load_bond(const BondRec *tab, uint32_t b) {
-    const uint4 q = *reinterpret_cast<const uint4 *>(tab + b);
-    BondRec r;
-    r.a_info = q.x; r.c = q.y;
-    r.w = __hiloint2double((int)q.w, (int)q.z);
-    return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -119,20 +125,19 @@ struct Lds {
     int *tot;          // [2][W]        per-wave totals (double buffered by round parity)
     uint32_t *chg;     // [2][W]
     uint32_t *misc;    // [16]
+    uint32_t *edges;   // [E]           compact edge table (CL mode only)
     uint32_t *cur;     // [W][N]        latest-cut copies (MAX scan)
     uint32_t *frozen;  // [ufwords]     bit per id: segment holds a longitudinal op
     uint32_t *froot;   // [ufwords]     bit per id: root is frozen
     uint32_t *parent;  // [ufcap]
-    __device__ static size_t words(uint32_t N, uint32_t nwords, uint32_t ufcap) {
-        return (size_t)nwords * (W + 2) + 4 * W + 16 + (size_t)W * N + 2 * ((ufcap + 31) / 32) + ufcap;
-    }
-    __device__ void carve(uint32_t *base, uint32_t N, uint32_t nwords, uint32_t ufcap) {
+    __device__ void carve(uint32_t *base, uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges) {
         state = base; base += nwords;
         scopy = base; base += W * nwords;
         touch = base; base += nwords;
         tot = (int *)base; base += 2 * W;
         chg = base; base += 2 * W;
         misc = base; base += 16;
+        edges = base; base += ledges;
         cur = base; base += (size_t)W * N;
         frozen = base; base += (ufcap + 31) / 32;
         froot = base; base += (ufcap + 31) / 32;
@@ -141,14 +146,42 @@ struct Lds {
 };
 enum { MISC_NCLUST = 0, MISC_ANYFROZEN = 1, MISC_LOOP_A = 2, MISC_LOOP_B = 3, MISC_LOOP_C = 4, MISC_LOOP_D = 5 };
 
+template <bool CL, int W>
+__device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, uint32_t b) {
+    Bd d;
+    if constexpr (CL) {
+        if (b < B.E) {
+            const uint32_t e = L.edges[b];
+            d.a = e & SSE_CE_VAR_MASK; d.c = (e >> 15) & SSE_CE_VAR_MASK;
+            d.kp = SSE_BOND_TWO_SITE | (((e >> 30) & 1u) << 2);
+            d.w = B.uniformJ ? B.wJ : B.edge_w[b];
+        } else if (b < B.E + B.N) {
+            d.a = b - B.E; d.c = SSE_NO_VAR; d.kp = SSE_BOND_TRANSVERSE; d.w = B.gamma;
+        } else {
+            d.a = b - B.E - B.N; d.c = SSE_NO_VAR; d.kp = SSE_BOND_LONGITUDINAL | (B.hpos << 2); d.w = B.wh;
+        }
+    } else {
+        const uint4 q = *reinterpret_cast<const uint4 *>(B.bonds + b);
+        d.a = q.x & SSE_VAR_MASK; d.c = q.y; d.kp = q.x >> SSE_INFO_SHIFT;
+        d.w = __hiloint2double((int)q.w, (int)q.z);
+    }
+    return d;
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+
+// slot index of (tile, wave, sub-round j, lane)
+template <int W, int K>
+__device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int lane) {
+    return tile * (uint32_t)(W * 64 * K) + (uint32_t)(wave * 64 * K + j * 64 + lane);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Diagonal pass.  Reference: DiagonalUpdater::make_diagonal_update_with_rng_and_state_ref
 // (qmc_traits/diagonal.rs:114-135) with metropolis_single_diagonal_update (:142-191), or the heat-bath
 // rule (qmc_traits/heatbath.rs:149-209) when HB.
-template <int W, bool HB>
+template <int W, int K, bool CL, bool HB>
 __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rng &rng, double beta, uint32_t M,
                               int &n_io, int &ntrans_io, uint32_t &gr) {
     constexpr int NT = W * 64;
@@ -157,135 +190,176 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
     uint32_t *ops = B.ops + (size_t)r * B.cap;
     const double beta_nb = beta * (double)B.Nb;
     const double hb_bw = beta * B.wtot;
-    const uint32_t tag = HB ? SSE_TAG_HEATBATH : SSE_TAG_DIAG;
+    uint32_t *mycopy = L.scopy + wave * nwords;
 
     for (uint32_t i = tid; i < nwords * W; i += NT) L.scopy[i] = L.state[i % nwords];
     __syncthreads();
 
-    const uint32_t nblk = (M + NT - 1) / NT;
-    int n_start = n_io, ntrans = ntrans_io;
+    const uint32_t ntiles = (M + NT * K - 1) / (NT * K);
+    int n_start = n_io, ntrans = 0;
 
-    // prologue: block 0 word + its bond record, its off-diagonal events into copies of later waves
-    uint32_t wnext = 0;
-    BondRec recnext;
-    recnext.a_info = 0; recnext.c = SSE_NO_VAR; recnext.w = 0.0;
-    {
-        uint32_t p = tid;
-        if (p < M) wnext = ops[p];
-        if (wnext) recnext = load_bond(B.bonds, sse_op_bond(wnext));
-        uint32_t x = sse_op_in(wnext) ^ sse_op_out(wnext);
-        if (x & 1u) { uint32_t v = rec_var(recnext); for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (v >> 5)], 1u << (v & 31)); }
-        if (x & 2u) { uint32_t v = recnext.c;        for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (v >> 5)], 1u << (v & 31)); }
+    uint32_t wnext[K];
+    // prologue: tile 0 words; their off-diagonal events go to the copies of later waves
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t p = slot_of<W, K>(0, wave, j, lane);
+        wnext[j] = p < M ? ops[p] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t x = sse_op_in(wnext[j]) ^ sse_op_out(wnext[j]);
+        if (x) {
+            const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wnext[j]));
+            if (x & 1u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (d.a >> 5)], 1u << (d.a & 31));
+            if (x & 2u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (d.c >> 5)], 1u << (d.c & 31));
+        }
     }
     __syncthreads();
 
-    for (uint32_t blk = 0; blk < nblk; ++blk) {
-        const uint32_t p = blk * NT + tid;
-        const bool valid = p < M;
-        const uint32_t word = wnext;
-        BondRec rec = recnext;
-        // prefetch the next tile
-        wnext = 0;
-        {
-            uint32_t pn = p + NT;
-            if (blk + 1 < nblk && pn < M) wnext = ops[pn];
-        }
-        const uint32_t xbits = sse_op_in(word) ^ sse_op_out(word);
-        const bool is_empty = valid && word == 0u;
-        const bool is_diag = word != 0u && xbits == 0u;
-
-        const uint4 rnd = rng.draw(tag, p);
-        uint32_t bsel = 0, sub = 0;
-        double num = 0.0, u = 0.0;
-        bool cand_ins = false, cand_rem = false;
-        bool hb_ok2 = false;
-        if (is_empty) {
-            if (HB) {
-                // stage 2 of the heat-bath rule does not depend on n: evaluate it once
-                const double c = u01(rnd.z) * B.wtot;
-                uint32_t lo = 0, hi = B.Nb;
-                while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (B.cumw[mid] < c) lo = mid + 1; else hi = mid; }
-                bsel = lo < B.Nb ? lo : B.Nb - 1;
-            } else {
-                bsel = __umulhi(rnd.x, B.Nb);
+    for (uint32_t tile = 0; tile < ntiles; ++tile) {
+        uint32_t word[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) word[j] = wnext[j];
+        if (tile + 1 < ntiles) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t pn = slot_of<W, K>(tile + 1, wave, j, lane);
+                wnext[j] = pn < M ? ops[pn] : 0u;
             }
-            rec = load_bond(B.bonds, bsel);
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) wnext[j] = 0u;
         }
-        // spin reads for insertion candidates: copy[wave] xor in-wave earlier events
-        const uint32_t va = rec_var(rec), vc = rec.c;
-        {
-            const uint64_t ev0 = __ballot((xbits & 1u) != 0u);
-            const uint64_t ev1 = __ballot((xbits & 2u) != 0u);
+
+        uint32_t bsel[K], sub[K], evA[K], evC[K], xb[K];
+        double num[K], u[K];
+        int cand[K]; // +1 insertion candidate, -1 removal candidate, 0 none
+        bool tr[K];
+        uint4 rnd = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
+            const bool valid = p < M;
+            const uint32_t wd = word[j];
+            xb[j] = sse_op_in(wd) ^ sse_op_out(wd);
+            const bool is_empty = valid && wd == 0u;
+            const bool is_diag = wd != 0u && xb[j] == 0u;
+            uint32_t r0, r1, r2 = 0;
+            if (HB) {
+                rnd = rng.draw(SSE_TAG_HEATBATH, p);
+                r0 = rnd.x; r1 = rnd.y; r2 = rnd.z;
+            } else {
+                // slots p and p^64 share one Philox call (include/sse_format.h)
+                if (K == 1 || (j & 1) == 0) rnd = rng.draw(SSE_TAG_DIAG, p & ~64u);
+                const bool hi = (K == 1) ? ((p & 64u) != 0u) : ((j & 1) != 0);
+                r0 = hi ? rnd.z : rnd.x; r1 = hi ? rnd.w : rnd.y;
+            }
+            uint32_t b = 0;
+            if (wd) b = sse_op_bond(wd);
+            else if (HB) {
+                if (is_empty) {
+                    const double c = u01(r2) * B.wtot;
+                    uint32_t lo = 0, hi2 = B.Nb;
+                    while (lo < hi2) { const uint32_t mid = lo + ((hi2 - lo) >> 1); if (B.cumw[mid] < c) lo = mid + 1; else hi2 = mid; }
+                    b = lo < B.Nb ? lo : B.Nb - 1;
+                }
+            } else b = __umulhi(r0, B.Nb);
+            const Bd d = decode_bond<CL, W>(B, L, b);
+            bsel[j] = b;
+            evA[j] = d.a; evC[j] = d.c;
+            tr[j] = bd_kind(d) == SSE_BOND_TRANSVERSE;
+            // spin reads for insertion candidates: own copy xor earlier events of this sub-round
             uint32_t sa = 0, sc = 0;
             if (is_empty) {
-                sa = (L.scopy[wave * nwords + (va >> 5)] >> (va & 31)) & 1u;
-                if (vc != SSE_NO_VAR) sc = (L.scopy[wave * nwords + (vc >> 5)] >> (vc & 31)) & 1u;
+                sa = (mycopy[d.a >> 5] >> (d.a & 31)) & 1u;
+                if (d.c != SSE_NO_VAR) sc = (mycopy[d.c >> 5] >> (d.c & 31)) & 1u;
             }
+            const uint64_t ev0 = __ballot((xb[j] & 1u) != 0u);
+            const uint64_t ev1 = __ballot((xb[j] & 2u) != 0u);
             uint64_t m = ev0;
             while (m) {
                 const int Ls = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const uint32_t vL = __builtin_amdgcn_readlane(va, Ls);
-                if (lane > Ls) { sa ^= (uint32_t)(va == vL); sc ^= (uint32_t)(vc == vL); }
+                const uint32_t vL = __builtin_amdgcn_readlane(d.a, Ls);
+                if (lane > Ls) { sa ^= (uint32_t)(d.a == vL); sc ^= (uint32_t)(d.c == vL); }
             }
             m = ev1;
             while (m) {
                 const int Ls = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const uint32_t vL = __builtin_amdgcn_readlane(vc, Ls);
-                if (lane > Ls) { sa ^= (uint32_t)(va == vL); sc ^= (uint32_t)(vc == vL); }
+                const uint32_t vL = __builtin_amdgcn_readlane(d.c, Ls);
+                if (lane > Ls) { sa ^= (uint32_t)(d.a == vL); sc ^= (uint32_t)(d.c == vL); }
             }
-            sub = sa | (sc << 1);
-        }
-        if (is_empty) {
-            const double w = bond_weight(rec, sub, sub);
-            if (HB) {
-                hb_ok2 = u01(rnd.y) * rec.w < w;
-                cand_ins = hb_ok2;
-                u = u01(rnd.x);
-            } else {
-                num = beta_nb * w;
-                cand_ins = w > 0.0;
-                u = u01(rnd.y);
+            // this sub-round's events become visible to the wave's later sub-rounds
+            if (K > 1 && (ev0 | ev1)) {
+                if (xb[j] & 1u) atomicXor(&mycopy[d.a >> 5], 1u << (d.a & 31));
+                if (xb[j] & 2u) atomicXor(&mycopy[d.c >> 5], 1u << (d.c & 31));
             }
-        } else if (is_diag) {
-            cand_rem = true;
-            if (HB) u = u01(rnd.x);
-            else { num = beta_nb * bond_weight(rec, sse_op_in(word), sse_op_in(word)); u = u01(rnd.y); }
+            sub[j] = sa | (sc << 1);
+            cand[j] = 0; num[j] = 0.0; u[j] = 0.0;
+            if (is_empty) {
+                const double w = bond_weight(d, sub[j], sub[j]);
+                if (HB) { cand[j] = (u01(r1) * d.w < w) ? 1 : 0; u[j] = u01(r0); }
+                else { num[j] = beta_nb * w; cand[j] = w > 0.0 ? 1 : 0; u[j] = u01(r1); }
+            } else if (is_diag) {
+                cand[j] = -1;
+                if (HB) u[j] = u01(r0);
+                else { num[j] = beta_nb * bond_weight(d, sse_op_in(wd), sse_op_in(wd)); u[j] = u01(r1); }
+            }
         }
 
         // ---- fixed point on n ----
-        int npref = n_start;
-        int dec = 0, dec_prev = 2;
+        int npref[K], dec[K], dec_prev[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { npref[j] = n_start; dec_prev[j] = 2; dec[j] = 0; }
         int tot_all = 0;
         bool first = true;
         for (;;) {
-            dec = 0;
-            if (cand_ins) {
-                const double den = (double)((int)M - npref);
-                if (HB) dec = (u * (den + hb_bw) < hb_bw) ? 1 : 0;
-                else dec = (u * den < num) ? 1 : 0;
-            } else if (cand_rem) {
-                const double den = (double)((int)M - npref + 1);
-                if (HB) dec = (u * (den + hb_bw) < den) ? -1 : 0;
-                else dec = (u * num < den) ? -1 : 0;
+            uint64_t im[K], rm[K];
+            bool changed = false;
+            int wtot = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                int d = 0;
+                if (cand[j] > 0) {
+                    const double den = (double)((int)M - npref[j]);
+                    if (HB) d = (u[j] * (den + hb_bw) < hb_bw) ? 1 : 0;
+                    else d = (u[j] * den < num[j]) ? 1 : 0;
+                } else if (cand[j] < 0) {
+                    const double den = (double)((int)M - npref[j] + 1);
+                    if (HB) d = (u[j] * (den + hb_bw) < den) ? -1 : 0;
+                    else d = (u[j] * num[j] < den) ? -1 : 0;
+                }
+                dec[j] = d;
+                changed |= (d != dec_prev[j]);
+                im[j] = __ballot(d > 0);
+                rm[j] = __ballot(d < 0);
+                wtot += popc64(im[j]) - popc64(rm[j]);
             }
-            const uint64_t im = __ballot(dec > 0), rm = __ballot(dec < 0);
-            const uint64_t cm = __ballot(dec != dec_prev);
+            const uint64_t cm = __ballot(changed);
             const int buf = gr & 1;
-            if (lane == 0) { L.tot[buf * W + wave] = popc64(im) - popc64(rm); L.chg[buf * W + wave] = cm != 0ull; }
+            if (lane == 0) { L.tot[buf * W + wave] = wtot; L.chg[buf * W + wave] = cm != 0ull; }
             __syncthreads();
             if (first) {
                 first = false;
-                // events of this tile -> copies of waves <= mine (all readers of this tile are done)
-                if (xbits & 1u) for (int w2 = 0; w2 <= wave; ++w2) atomicXor(&L.scopy[w2 * nwords + (va >> 5)], 1u << (va & 31));
-                if (xbits & 2u) for (int w2 = 0; w2 <= wave; ++w2) atomicXor(&L.scopy[w2 * nwords + (vc >> 5)], 1u << (vc & 31));
-                // events of the next tile -> copies of waves > mine (visible after the next barrier)
-                recnext.a_info = 0; recnext.c = SSE_NO_VAR; recnext.w = 0.0;
-                if (wnext) recnext = load_bond(B.bonds, sse_op_bond(wnext));
-                const uint32_t xn = sse_op_in(wnext) ^ sse_op_out(wnext);
-                if (xn & 1u) { uint32_t v = rec_var(recnext); for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (v >> 5)], 1u << (v & 31)); }
-                if (xn & 2u) { uint32_t v = recnext.c;        for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (v >> 5)], 1u << (v & 31)); }
+                // events of this tile -> copies of earlier waves (all readers of this tile are done);
+                // for K == 1 also the wave's own copy
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int wend = (K > 1) ? wave : wave + 1;
+                    if (xb[j] & 1u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&L.scopy[w2 * nwords + (evA[j] >> 5)], 1u << (evA[j] & 31));
+                    if (xb[j] & 2u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&L.scopy[w2 * nwords + (evC[j] >> 5)], 1u << (evC[j] & 31));
+                }
+                // events of the next tile -> copies of later waves (visible after the next barrier)
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const uint32_t xn = sse_op_in(wnext[j]) ^ sse_op_out(wnext[j]);
+                    if (xn) {
+                        const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wnext[j]));
+                        if (xn & 1u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (d.a >> 5)], 1u << (d.a & 31));
+                        if (xn & 2u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (d.c >> 5)], 1u << (d.c & 31));
+                    }
+                }
             }
             int base = 0; tot_all = 0; uint32_t anychg = 0;
 #pragma unroll
@@ -296,22 +370,29 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
                 anychg |= L.chg[buf * W + w2];
             }
             gr++;
-            if (dec_prev != 2 && !anychg) break;
-            npref = n_start + base + popc64(im & lanemask_lt(lane)) - popc64(rm & lanemask_lt(lane));
-            dec_prev = dec;
+            if (dec_prev[0] != 2 && !anychg) break;
+            int run = n_start + base;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                npref[j] = run + popc64(im[j] & lanemask_lt(lane)) - popc64(rm[j] & lanemask_lt(lane));
+                run += popc64(im[j]) - popc64(rm[j]);
+                dec_prev[j] = dec[j];
+            }
         }
         // ---- commit ----
-        if (dec != 0) {
-            const uint32_t neww = dec > 0 ? sse_op_make(bsel, sub, sub) : 0u;
-            ops[p] = neww;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (dec[j] != 0) {
+                const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
+                ops[p] = dec[j] > 0 ? sse_op_make(bsel[j], sub[j], sub[j]) : 0u;
+            }
+            ntrans += popc64(__ballot(dec[j] > 0 && tr[j])) - popc64(__ballot(dec[j] < 0 && tr[j]));
         }
-        const bool tr = rec_kind(rec) == SSE_BOND_TRANSVERSE;
-        ntrans += popc64(__ballot(dec > 0 && tr)) - popc64(__ballot(dec < 0 && tr));
         n_start += tot_all;
     }
     // per-wave transverse deltas -> block total
     __syncthreads();
-    if (lane == 0) L.tot[wave] = ntrans - ntrans_io;
+    if (lane == 0) L.tot[wave] = ntrans;
     __syncthreads();
     int dt = 0;
 #pragma unroll
@@ -343,106 +424,149 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
     }
 }
 
-// Segment scan shared by cluster build and apply.  For the tile's ops it yields, per lane, the segment ids
+// Segment scan shared by cluster build and apply.  For the tile's ops it yields, per slot, the segment ids
 // of its legs (seg_a for var a, seg_c for var c, id_own for a cut's outgoing segment).
 // Segment ids: [0,N) = worldline part containing p=0 (placeholder), N+k = segment opened by the k-th cut.
-template <int W, bool APPLY>
+template <int W, int K, bool CL, bool APPLY>
 __device__ void cluster_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t M, uint32_t *parent,
                              uint32_t *frozen, uint32_t &gr, uint32_t &ncuts_out) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t N = B.N;
     uint32_t *ops = B.ops + (size_t)r * B.cap;
+    uint32_t *mycur = L.cur + (size_t)wave * N;
     for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) L.cur[i] = 0u;
     __syncthreads();
-    const uint32_t nblk = (M + NT - 1) / NT;
+    const uint32_t ntiles = (M + NT * K - 1) / (NT * K);
     uint32_t cutbase = 0;
-    // deferred phase-2 writes of the previous tile
-    bool pend = false; uint32_t pend_v = 0, pend_id = 0;
-    uint32_t wnext = (tid < M) ? ops[tid] : 0u;
-    for (uint32_t blk = 0; blk < nblk; ++blk) {
-        const uint32_t p = blk * NT + tid;
-        const uint32_t word = wnext;
-        wnext = 0;
-        if (blk + 1 < nblk && p + NT < M) wnext = ops[p + NT];
-        BondRec rec; rec.a_info = 0; rec.c = SSE_NO_VAR; rec.w = 0.0;
-        if (word) rec = load_bond(B.bonds, sse_op_bond(word));
-        const uint32_t kind = rec_kind(rec);
-        const uint32_t va = rec_var(rec), vc = rec.c;
-        const bool nonempty = word != 0u;
-        const bool iscut = nonempty && kind == SSE_BOND_TRANSVERSE;
-        const uint64_t cutmask = __ballot(iscut);
+    // deferred writes of the previous tile's cuts into the copies of earlier waves
+    uint32_t pend_v[K], pend_id[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { pend_v[j] = 0; pend_id[j] = 0; }
+    uint32_t wnext[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t p = slot_of<W, K>(0, wave, j, lane);
+        wnext[j] = p < M ? ops[p] : 0u;
+    }
+    for (uint32_t tile = 0; tile < ntiles; ++tile) {
+        uint32_t word[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) word[j] = wnext[j];
+        if (tile + 1 < ntiles) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t pn = slot_of<W, K>(tile + 1, wave, j, lane);
+                wnext[j] = pn < M ? ops[pn] : 0u;
+            }
+        }
+        uint32_t va[K], vc[K], kind[K];
+        uint64_t cutmask[K];
+        int wcuts = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            va[j] = 0; vc[j] = SSE_NO_VAR; kind[j] = SSE_BOND_TWO_SITE;
+            if (word[j]) {
+                const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(word[j]));
+                va[j] = d.a; vc[j] = d.c; kind[j] = bd_kind(d);
+            }
+            cutmask[j] = __ballot(word[j] != 0u && kind[j] == SSE_BOND_TRANSVERSE);
+            wcuts += popc64(cutmask[j]);
+        }
         const int buf = gr & 1;
-        if (lane == 0) L.tot[buf * W + wave] = popc64(cutmask);
+        if (lane == 0) L.tot[buf * W + wave] = wcuts;
         __syncthreads(); // (A)
         gr++;
         uint32_t wbase = 0, total = 0;
 #pragma unroll
         for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)L.tot[buf * W + w2]; if (w2 < wave) wbase += t; total += t; }
-        // previous tile's cuts become visible to waves <= their own (everyone finished reading that tile)
-        if (pend) for (int w2 = 0; w2 <= wave; ++w2) atomicMax(&L.cur[w2 * N + pend_v], pend_id);
-        const uint32_t first_id = N + cutbase + wbase;
-        const uint32_t id_own = first_id + popc64(cutmask & lanemask_lt(lane));
-        if (iscut) {
-            if (!APPLY) parent[id_own] = id_own;
-            for (int w2 = wave + 1; w2 < W; ++w2) atomicMax(&L.cur[w2 * N + va], id_own);
-        }
-        pend = iscut; pend_v = va; pend_id = id_own;
-        __syncthreads(); // (B)
-        uint32_t seg_a = 0, seg_c = 0;
-        if (nonempty) {
-            seg_a = L.cur[wave * N + va];
-            if (vc != SSE_NO_VAR) seg_c = L.cur[wave * N + vc];
-        }
+        // previous tile's cuts become visible to earlier waves (everyone finished reading that tile)
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (pend_id[j]) for (int w2 = 0; w2 < wave; ++w2) atomicMax(&L.cur[(size_t)w2 * N + pend_v[j]], pend_id[j]);
+        uint32_t id_own[K];
+        uint32_t first_id[K];
         {
-            uint64_t m = cutmask;
-            uint32_t idL = first_id;
-            while (m) {
-                const int Ls = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const uint32_t vL = __builtin_amdgcn_readlane(va, Ls);
-                if (lane > Ls) { if (va == vL) seg_a = idL; if (vc == vL) seg_c = idL; }
-                idL++;
+            uint32_t run = N + cutbase + wbase;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                first_id[j] = run;
+                id_own[j] = run + popc64(cutmask[j] & lanemask_lt(lane));
+                run += popc64(cutmask[j]);
+                const bool iscut = (cutmask[j] >> lane) & 1ull;
+                if (iscut) {
+                    if (!APPLY) parent[id_own[j]] = id_own[j];
+                    for (int w2 = wave + 1; w2 < W; ++w2) atomicMax(&L.cur[(size_t)w2 * N + va[j]], id_own[j]);
+                }
+                pend_v[j] = va[j];
+                pend_id[j] = iscut ? id_own[j] : 0u;
             }
         }
-        if (nonempty) {
-            if (seg_a == 0u) seg_a = va;
-            if (vc != SSE_NO_VAR && seg_c == 0u) seg_c = vc;
-            if (!APPLY) {
-                atomicOr(&L.touch[va >> 5], 1u << (va & 31));
-                if (kind == SSE_BOND_TWO_SITE) {
-                    atomicOr(&L.touch[vc >> 5], 1u << (vc & 31));
-                    uf_union(parent, seg_a, seg_c);
-                } else if (kind == SSE_BOND_LONGITUDINAL) {
-                    atomicOr(&frozen[seg_a >> 5], 1u << (seg_a & 31));
+        __syncthreads(); // (B)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool nonempty = word[j] != 0u;
+            const bool iscut = (cutmask[j] >> lane) & 1ull;
+            uint32_t seg_a = 0, seg_c = 0;
+            if (nonempty) {
+                seg_a = mycur[va[j]];
+                if (vc[j] != SSE_NO_VAR) seg_c = mycur[vc[j]];
+            }
+            {
+                uint64_t m = cutmask[j];
+                uint32_t idL = first_id[j];
+                while (m) {
+                    const int Ls = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const uint32_t vL = __builtin_amdgcn_readlane(va[j], Ls);
+                    if (lane > Ls) { if (va[j] == vL) seg_a = idL; if (vc[j] == vL) seg_c = idL; }
+                    idL++;
                 }
-            } else {
-                uint32_t in = sse_op_in(word), out = sse_op_out(word);
-                const uint32_t fa = parent[seg_a];
-                if (iscut) {
-                    in ^= fa;
-                    out ^= parent[id_own];
-                } else if (kind == SSE_BOND_TWO_SITE) {
-                    const uint32_t f2 = fa | (parent[seg_c] << 1);
-                    in ^= f2; out ^= f2;
+            }
+            // this sub-round's cuts become visible to the wave's later sub-rounds (ids grow with p)
+            if (iscut) atomicMax(&mycur[va[j]], id_own[j]);
+            if (nonempty) {
+                if (seg_a == 0u) seg_a = va[j];
+                if (vc[j] != SSE_NO_VAR && seg_c == 0u) seg_c = vc[j];
+                if (!APPLY) {
+                    atomicOr(&L.touch[va[j] >> 5], 1u << (va[j] & 31));
+                    if (kind[j] == SSE_BOND_TWO_SITE) {
+                        atomicOr(&L.touch[vc[j] >> 5], 1u << (vc[j] & 31));
+                        uf_union(parent, seg_a, seg_c);
+                    } else if (kind[j] == SSE_BOND_LONGITUDINAL) {
+                        atomicOr(&frozen[seg_a >> 5], 1u << (seg_a & 31));
+                    }
                 } else {
-                    in ^= fa; out ^= fa;
+                    const uint32_t wd = word[j];
+                    uint32_t in = sse_op_in(wd), out = sse_op_out(wd);
+                    const uint32_t fa = parent[seg_a];
+                    if (iscut) {
+                        in ^= fa;
+                        out ^= parent[id_own[j]];
+                    } else if (kind[j] == SSE_BOND_TWO_SITE) {
+                        const uint32_t f2 = fa | (parent[seg_c] << 1);
+                        in ^= f2; out ^= f2;
+                    } else {
+                        in ^= fa; out ^= fa;
+                    }
+                    const uint32_t neww = (wd & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
+                    if (neww != wd) ops[slot_of<W, K>(tile, wave, j, lane)] = neww;
                 }
-                const uint32_t neww = (word & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
-                if (neww != word) ops[p] = neww;
             }
         }
         cutbase += total;
     }
     __syncthreads();
-    if (pend) for (int w2 = 0; w2 <= wave; ++w2) atomicMax(&L.cur[w2 * N + pend_v], pend_id);
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (pend_id[j]) for (int w2 = 0; w2 < wave; ++w2) atomicMax(&L.cur[(size_t)w2 * N + pend_v[j]], pend_id[j]);
     __syncthreads();
     ncuts_out = cutbase;
 }
 
 // Cluster update.  Reference: ClusterUpdater::flip_each_cluster_rng (qmc_traits/cluster.rs:36-172) with the
 // longitudinal weight function of qmc_ising.rs:759-775.  Returns the number of clusters.
-template <int W, bool UF_GLOBAL>
+template <int W, int K, bool CL, bool UF_GLOBAL>
 __device__ uint32_t cluster_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rng &rng, double prob, uint32_t M,
                                  int n, int ntrans, uint32_t &gr) {
     constexpr int NT = W * 64;
@@ -466,9 +590,16 @@ __device__ uint32_t cluster_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const
     __syncthreads();
     // ---- build: label legs with segment ids, union through non-boundary ops ----
     uint32_t ncuts = 0;
-    cluster_scan<W, false>(B, L, r, M, parent, frozen, gr, ncuts);
-    // wrap-around: the part of worldline v before its first cut continues the segment of its last cut
-    for (uint32_t v = tid; v < N; v += NT) { const uint32_t last = L.cur[v]; if (last) uf_union(parent, v, last); }
+    cluster_scan<W, K, CL, false>(B, L, r, M, parent, frozen, gr, ncuts);
+    // wrap-around: the part of worldline v before its first cut continues the segment of its last cut.
+    // A wave applies its own cuts to its own copy and to every other wave's copy, so after the scan the
+    // last cut on v is the maximum over all copies.
+    for (uint32_t v = tid; v < N; v += NT) {
+        uint32_t last = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < W; ++w2) { const uint32_t x = L.cur[(size_t)w2 * N + v]; last = x > last ? x : last; }
+        if (last) uf_union(parent, v, last);
+    }
     __syncthreads();
     // ---- flatten: parent[i] := exact root (no union runs any more), frozen marks move to roots ----
     for (uint32_t i = tid; i < S; i += NT) {
@@ -505,7 +636,7 @@ __device__ uint32_t cluster_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const
     __syncthreads();
     // ---- apply (cluster.rs:139-167) ----
     uint32_t ncuts2 = 0;
-    cluster_scan<W, true>(B, L, r, M, parent, frozen, gr, ncuts2);
+    cluster_scan<W, K, CL, true>(B, L, r, M, parent, frozen, gr, ncuts2);
     // p=0 state follows the placeholder segment of each touched variable
     for (uint32_t i = tid; i < nwords; i += NT) {
         uint32_t x = 0;
@@ -518,20 +649,24 @@ __device__ uint32_t cluster_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const
 }
 
 // touched-variable scan for launches that flip free spins without a preceding cluster pass
-template <int W>
+template <int W, bool CL>
 __device__ void touch_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t M) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
     const uint32_t *ops = B.ops + (size_t)r * B.cap;
     for (uint32_t i = tid; i < B.nwords; i += NT) L.touch[i] = 0u;
     __syncthreads();
-    for (uint32_t p = tid; p < M; p += NT) {
-        const uint32_t word = ops[p];
-        if (!word) continue;
-        const BondRec rec = load_bond(B.bonds, sse_op_bond(word));
-        const uint32_t va = rec_var(rec);
-        atomicOr(&L.touch[va >> 5], 1u << (va & 31));
-        if (rec.c != SSE_NO_VAR) atomicOr(&L.touch[rec.c >> 5], 1u << (rec.c & 31));
+    for (uint32_t p0 = 0; p0 < M; p0 += 4 * NT) {
+        uint32_t wd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t p = p0 + j * NT + tid; wd[j] = p < M ? ops[p] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!wd[j]) continue;
+            const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
+            atomicOr(&L.touch[d.a >> 5], 1u << (d.a & 31));
+            if (d.c != SSE_NO_VAR) atomicOr(&L.touch[d.c >> 5], 1u << (d.c & 31));
+        }
     }
     __syncthreads();
 }
@@ -561,33 +696,42 @@ __device__ void free_spin_pass(const DevBatch &B, Lds<W> &L, const Rng &rng) {
 //   get_nth_p (:76-87, an O(n) list walk)        -> tile-wise ballot/popcount rank search
 //   get_next/previous_p_for_rel_var (:51-54)     -> tile-wise search along the worldline direction
 // Returns the number of vertices visited.
-template <int W>
+template <int W, bool CL>
 __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rng &rng, uint32_t M, int n, uint32_t &gr,
                               uint32_t &err) {
     constexpr int NT = W * 64;
+    constexpr int U = 4; // independent loads in flight per thread during searches
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *ops = B.ops + (size_t)r * B.cap;
     if (n == 0) return 0u;
     const uint4 o0 = rng.draw(SSE_TAG_LOOP, 0u);
     const uint32_t nth = __umulhi(o0.x, (uint32_t)n);
-    // ---- start vertex: the nth occupied slot in p order ----
-    const uint32_t nblk = (M + NT - 1) / NT;
+    // ---- start vertex: the nth occupied slot in p order (chunks of U*NT slots, wave-major inside) ----
     uint32_t cbase = 0;
     if (tid == 0) L.misc[MISC_LOOP_A] = 0xFFFFFFFFu;
     __syncthreads();
-    for (uint32_t blk = 0; blk < nblk; ++blk) {
-        const uint32_t p = blk * NT + tid;
-        const uint32_t word = p < M ? ops[p] : 0u;
-        const uint64_t occ = __ballot(word != 0u);
+    for (uint32_t q0 = 0; q0 < M; q0 += U * NT) {
+        uint32_t wd[U];
+        uint64_t occ[U];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < U; ++j) { const uint32_t p = q0 + (uint32_t)(wave * 64 * U + j * 64 + lane); wd[j] = p < M ? ops[p] : 0u; }
+#pragma unroll
+        for (int j = 0; j < U; ++j) { occ[j] = __ballot(wd[j] != 0u); cnt += popc64(occ[j]); }
         const int buf = gr & 1;
-        if (lane == 0) L.tot[buf * W + wave] = popc64(occ);
+        if (lane == 0) L.tot[buf * W + wave] = cnt;
         __syncthreads();
         gr++;
         uint32_t wbase = 0, total = 0;
 #pragma unroll
         for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)L.tot[buf * W + w2]; if (w2 < wave) wbase += t; total += t; }
-        const uint32_t myrank = cbase + wbase + popc64(occ & lanemask_lt(lane));
-        if (word != 0u && myrank == nth) L.misc[MISC_LOOP_A] = p;
+        uint32_t run = cbase + wbase;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t myrank = run + popc64(occ[j] & lanemask_lt(lane));
+            if (wd[j] != 0u && myrank == nth) L.misc[MISC_LOOP_A] = q0 + (uint32_t)(wave * 64 * U + j * 64 + lane);
+            run += popc64(occ[j]);
+        }
         cbase += total;
         if (cbase > nth) break;
     }
@@ -596,26 +740,27 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
     if (p0 == 0xFFFFFFFFu) { err = 2u; return 0u; } // n inconsistent with the op-string
     uint32_t rel0, side0;
     {
-        const BondRec rec0 = load_bond(B.bonds, sse_op_bond(ops[p0]));
-        const uint32_t k0 = rec0.c != SSE_NO_VAR ? 2u : 1u;
+        const Bd d0 = decode_bond<CL, W>(B, L, sse_op_bond(ops[p0]));
+        const uint32_t k0 = d0.c != SSE_NO_VAR ? 2u : 1u;
         rel0 = __umulhi(o0.y, k0);
         side0 = (o0.z >> 31) ? 0u : 1u; // gen() true -> Inputs (directed_loop.rs:153-157)
     }
     uint32_t p = p0, rel = rel0, side = side0, visited = 0;
     const uint32_t max_steps = 8u * M + 64u;
+    bool finished = false;
     for (uint32_t step = 1; step <= max_steps; ++step) {
         // ---- vertex update by thread 0 ----
         if (tid == 0) {
             const uint32_t word = ops[p];
-            const BondRec rec = load_bond(B.bonds, sse_op_bond(word));
-            const uint32_t k = rec.c != SSE_NO_VAR ? 2u : 1u;
+            const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(word));
+            const uint32_t k = d.c != SSE_NO_VAR ? 2u : 1u;
             uint32_t in_e = sse_op_in(word), out_e = sse_op_out(word);
             if (side == 0u) in_e ^= 1u << rel; else out_e ^= 1u << rel;
             double wl[4], total = 0.0;
             for (uint32_t leg = 0; leg < 2u * k; ++leg) {
                 uint32_t i2 = in_e, o2 = out_e;
                 if (leg < k) i2 ^= 1u << leg; else o2 ^= 1u << (leg - k);
-                wl[leg] = bond_weight(rec, i2, o2);
+                wl[leg] = bond_weight(d, i2, o2);
                 total += wl[leg];
             }
             const uint4 o = rng.draw(SSE_TAG_LOOP, step);
@@ -629,7 +774,7 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
             if (xside == 0u) in_e ^= 1u << xrel; else out_e ^= 1u << xrel;
             ops[p] = (word & ~0xFu) | in_e | (out_e << SSE_OP_OUT_SHIFT);
             const bool closed = (p == p0 && xrel == rel0 && xside == side0);
-            const uint32_t var = xrel == 0u ? rec_var(rec) : rec.c;
+            const uint32_t var = xrel == 0u ? d.a : d.c;
             L.misc[MISC_LOOP_A] = closed ? 1u : 0u;
             L.misc[MISC_LOOP_B] = var;
             L.misc[MISC_LOOP_C] = xside | (xrel << 1) | ((((xside == 1u ? out_e : in_e) >> xrel) & 1u) << 2);
@@ -637,46 +782,57 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
         }
         __syncthreads();
         visited++;
-        if (L.misc[MISC_LOOP_A]) break;
+        if (L.misc[MISC_LOOP_A]) { finished = true; break; }
         const uint32_t var = L.misc[MISC_LOOP_B];
         const uint32_t info = L.misc[MISC_LOOP_C];
         const uint32_t xside = info & 1u, newbit = (info >> 2) & 1u;
         const bool forward = xside == 1u;
         // ---- search the next op on worldline `var`, distance 1..M (distance M = the op itself) ----
         uint32_t found = 0xFFFFFFFFu;
-        for (uint32_t d0 = 1; d0 <= M; d0 += NT) {
-            const uint32_t d = d0 + tid;
-            bool match = false;
-            if (d <= M) {
-                uint32_t q = forward ? p + d : p + M - d;
-                if (q >= M) q -= M;
-                const uint32_t word = ops[q];
-                if (word) {
-                    const BondRec rec = load_bond(B.bonds, sse_op_bond(word));
-                    match = rec_var(rec) == var || rec.c == var;
+        for (uint32_t d0 = 1; d0 <= M; d0 += U * NT) {
+            uint32_t wd[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t d = d0 + (uint32_t)(j * NT + tid);
+                wd[j] = 0u;
+                if (d <= M) {
+                    uint32_t q = forward ? p + d : p + M - d;
+                    if (q >= M) q -= M;
+                    wd[j] = ops[q];
                 }
             }
-            const uint64_t mm = __ballot(match);
-            if (mm && lane == 0) atomicMin(&L.misc[MISC_LOOP_D], d0 + (uint32_t)(wave * 64) + (uint32_t)(__ffsll((long long)mm) - 1));
+            uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = U - 1; j >= 0; --j) {
+                bool match = false;
+                if (wd[j]) {
+                    const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
+                    match = d.a == var || d.c == var;
+                }
+                const uint64_t mm = __ballot(match);
+                if (mm) best = d0 + (uint32_t)(j * NT + wave * 64) + (uint32_t)(__ffsll((long long)mm) - 1);
+            }
+            if (best != 0xFFFFFFFFu && lane == 0) atomicMin(&L.misc[MISC_LOOP_D], best);
             __syncthreads();
             found = L.misc[MISC_LOOP_D];
             __syncthreads();
             if (found != 0xFFFFFFFFu) break;
         }
-        if (found == 0xFFFFFFFFu) { err = 2u; break; }
+        if (found == 0xFFFFFFFFu) { err = 2u; finished = true; break; }
         uint32_t q = forward ? p + found : p + M - found;
-        bool wrapped = forward ? (q >= M) : (found > p);
+        const bool wrapped = forward ? (q >= M) : (found > p);
         if (q >= M) q -= M;
-        const BondRec recq = load_bond(B.bonds, sse_op_bond(ops[q]));
-        const uint32_t nrel = rec_var(recq) == var ? 0u : 1u;
+        const Bd dq = decode_bond<CL, W>(B, L, sse_op_bond(ops[q]));
+        const uint32_t nrel = dq.a == var ? 0u : 1u;
         if (wrapped && tid == 0) { // directed_loop.rs:276-288
             const uint32_t wi = var >> 5, bi = var & 31;
             L.state[wi] = (L.state[wi] & ~(1u << bi)) | (newbit << bi);
         }
         const uint32_t nside = xside ^ 1u;
-        if (q == p0 && nrel == rel0 && nside == side0) break; // :293
+        if (q == p0 && nrel == rel0 && nside == side0) { finished = true; break; } // :293
         p = q; rel = nrel; side = nside;
     }
+    if (!finished) err = 3u;
     __syncthreads();
     return visited;
 }
@@ -685,15 +841,19 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
 // One launch = nsteps timesteps of every replica.  Reference drivers: QmcIsingGraph::timestep
 // (qmc_ising.rs:644-795), Qmc::timestep (qmc_runner.rs:363-377), measurement loop
 // QmcStepper::timesteps_measure_with_self (qmc_traits/qmc_stepper.rs:133-162).
-template <int W>
+// PHASE only tags the symbol (0 = measured path, 1 = data preparation) so that profilers can tell the
+// two apart; the code is identical.
+template <int W, int K, bool CL, int PHASE>
 __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) {
     extern __shared__ __align__(16) uint32_t lds_raw[];
     constexpr int NT = W * 64;
     Lds<W> L;
-    L.carve(lds_raw, B.N, B.nwords, B.lds_ufcap);
+    L.carve(lds_raw, B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u);
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
     for (uint32_t i = tid; i < B.nwords; i += NT) L.state[i] = B.state[(size_t)r * B.nwords + i];
+    if constexpr (CL)
+        for (uint32_t i = tid; i < B.E; i += NT) L.edges[i] = B.edges_compact[i];
     __syncthreads();
     int n = (int)B.n[r], ntrans = (int)B.ntrans[r];
     uint32_t M = B.cutoff[r], err = B.err[r], gr = 0, last_out = 0;
@@ -704,8 +864,8 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
         if (err) break;
         if (A.domask & SSE_DO_DIAG) {
             const Rng rng = make_rng(B, r, epoch);
-            if (A.domask & SSE_DO_HEATBATH) diagonal_pass<W, true>(B, L, r, rng, beta, M, n, ntrans, gr);
-            else diagonal_pass<W, false>(B, L, r, rng, beta, M, n, ntrans, gr);
+            if (A.domask & SSE_DO_HEATBATH) diagonal_pass<W, K, CL, true>(B, L, r, rng, beta, M, n, ntrans, gr);
+            else diagonal_pass<W, K, CL, false>(B, L, r, rng, beta, M, n, ntrans, gr);
             epoch++;
             a5 += M;
             if (A.domask & SSE_DO_GROW) { // qmc_ising.rs:786, qmc_runner.rs:197
@@ -715,25 +875,25 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
         }
         if (A.domask & SSE_DO_LOOP) {
             const Rng rng = make_rng(B, r, epoch);
-            last_out = loop_pass<W>(B, L, r, rng, M, n, gr, err);
+            last_out = loop_pass<W, CL>(B, L, r, rng, M, n, gr, err);
             epoch++;
             a4 += last_out;
             if (err) break;
         }
         if (A.domask & SSE_DO_CLUSTER) {
             const Rng rng = make_rng(B, r, epoch);
-            if (B.N + (uint32_t)ntrans <= B.lds_ufcap) last_out = cluster_pass<W, false>(B, L, r, rng, A.prob, M, n, ntrans, gr);
-            else last_out = cluster_pass<W, true>(B, L, r, rng, A.prob, M, n, ntrans, gr);
+            if (B.N + (uint32_t)ntrans <= B.lds_ufcap) last_out = cluster_pass<W, K, CL, false>(B, L, r, rng, A.prob, M, n, ntrans, gr);
+            else last_out = cluster_pass<W, K, CL, true>(B, L, r, rng, A.prob, M, n, ntrans, gr);
             epoch++;
             a4 += (uint64_t)n;
         }
         if (A.domask & SSE_DO_FREE) {
             const Rng rng = make_rng(B, r, epoch);
-            if (!(A.domask & SSE_DO_CLUSTER)) touch_scan<W>(B, L, r, M);
+            if (!(A.domask & SSE_DO_CLUSTER)) touch_scan<W, CL>(B, L, r, M);
             free_spin_pass<W>(B, L, rng);
             epoch++;
         }
-        if (A.sampling_freq && (step + 1) % A.sampling_freq == 0) {
+        if (A.sampling_freq && (A.step0 + step + 1) % A.sampling_freq == 0) {
             if (tid == 0) L.misc[MISC_LOOP_A] = 0u;
             __syncthreads();
             uint32_t up = 0;
@@ -756,41 +916,38 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
     }
 }
 
-// Verify::verify (qmc_ising.rs:829-860; op_container.rs:137-159) and bond counts, one thread per replica
-// (debug API, not on the hot path).  ok[r] = 1 iff every op has non-zero weight, the propagated state matches
-// every op's inputs, periodicity holds and the occupied-slot count equals n.
-__global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*/, uint8_t *ok) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= B.R) return;
-    uint32_t *s = scratch_state + (size_t)r * B.nwords;
-    const uint32_t *s0 = B.state + (size_t)r * B.nwords;
-    for (uint32_t i = 0; i < B.nwords; ++i) s[i] = s0[i];
-    const uint32_t *ops = B.ops + (size_t)r * B.cap;
-    const uint32_t M = B.cutoff[r];
-    bool good = true;
-    uint32_t count = 0, ntr = 0;
-    for (uint32_t p = 0; p < B.cap; ++p) {
-        const uint32_t w = ops[p];
-        if (!w) continue;
-        if (p >= M) { good = false; break; }
-        count++;
-        const uint32_t b = sse_op_bond(w);
-        if (b >= B.Nb) { good = false; break; }
-        const BondRec rec = load_bond(B.bonds, b);
-        const uint32_t in = sse_op_in(w), out = sse_op_out(w);
-        if (!(bond_weight(rec, in, out) > 2.220446049250313e-16)) good = false;
-        if (rec_kind(rec) == SSE_BOND_TRANSVERSE) ntr++;
-        const uint32_t a = rec_var(rec), c = rec.c;
-        if (((s[a >> 5] >> (a & 31)) & 1u) != (in & 1u)) good = false;
-        s[a >> 5] = (s[a >> 5] & ~(1u << (a & 31))) | ((out & 1u) << (a & 31));
-        if (c != SSE_NO_VAR) {
-            if (((s[c >> 5] >> (c & 31)) & 1u) != ((in >> 1) & 1u)) good = false;
-            s[c >> 5] = (s[c >> 5] & ~(1u << (c & 31))) | (((out >> 1) & 1u) << (c & 31));
-        } else if ((in | out) & 2u) good = false;
+struct LaunchCfg {
+    uint32_t W, K, CL, phase;
+    size_t lds_bytes;
+    hipStream_t stream;
+};
+// one translation unit per W (sweep_w*.hip) defines these
+hipError_t launch_sweep_w1(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
+hipError_t launch_sweep_w4(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
+hipError_t launch_sweep_w8(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
+hipError_t launch_sweep_w16(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
+
+template <int W, int K, bool CL, int PHASE>
+hipError_t launch_one(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel<W, K, CL, PHASE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sweep_kernel<W, K, CL, PHASE>), dim3(B.R), dim3(W * 64), c.lds_bytes, c.stream, B, A);
+    return hipGetLastError();
+}
+template <int W>
+hipError_t launch_w(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
+    if (c.phase) { // data-preparation symbol: only the default geometry
+        if (c.K == 4 && c.CL) return launch_one<W, 4, true, 1>(c, B, A);
+        if (c.K == 4 && !c.CL) return launch_one<W, 4, false, 1>(c, B, A);
     }
-    for (uint32_t i = 0; i < B.nwords; ++i) if (s[i] != s0[i]) good = false;
-    if (count != B.n[r] || ntr != B.ntrans[r]) good = false;
-    ok[r] = good ? 1 : 0;
+    if (c.K == 4 && c.CL) return launch_one<W, 4, true, 0>(c, B, A);
+    if (c.K == 4 && !c.CL) return launch_one<W, 4, false, 0>(c, B, A);
+    if (c.K == 1 && c.CL) return launch_one<W, 1, true, 0>(c, B, A);
+    if (c.K == 1 && !c.CL) return launch_one<W, 1, false, 0>(c, B, A);
+    if (c.K == 2 && c.CL) return launch_one<W, 2, true, 0>(c, B, A);
+    if (c.K == 2 && !c.CL) return launch_one<W, 2, false, 0>(c, B, A);
+    return hipErrorInvalidValue;
 }
 
 } // namespace sse

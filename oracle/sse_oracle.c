@@ -60,6 +60,13 @@ static void draw(const ora_replica *r, uint32_t tag, uint32_t index, uint32_t ou
     uint32_t key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)};
     ora_philox4x32_10(ctr, key, out);
 }
+/* Metropolis diagonal pass: one Philox call serves the slot pair (p, p^64): index = p with bit 6 cleared,
+ * words (0,1) for the slot with bit 6 clear, words (2,3) for the other (include/sse_format.h). */
+static void draw_diag(const ora_replica *r, uint32_t p, uint32_t out[2]) {
+    uint32_t o[4];
+    draw(r, SSE_TAG_DIAG, p & ~64u, o);
+    if (p & 64u) { out[0] = o[2]; out[1] = o[3]; } else { out[0] = o[0]; out[1] = o[1]; }
+}
 static inline double u01(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
 static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
@@ -198,8 +205,8 @@ void ora_diagonal_update(ora_replica *r, double beta) {
     for (uint32_t p = 0; p < M; ++p) {
         uint32_t w = r->ops[p];
         if (w == SSE_OP_EMPTY) {
-            uint32_t o[4];
-            draw(r, SSE_TAG_DIAG, p, o);
+            uint32_t o[2];
+            draw_diag(r, p, o);
             uint32_t b = mulhi32(o[0], m->nbonds);
             uint32_t s = substate(r, b);
             double num = beta_nb * bond_weight(m, b, s, s);
@@ -209,8 +216,8 @@ void ora_diagonal_update(ora_replica *r, double beta) {
                 r->n += 1;
             }
         } else if (sse_op_is_diagonal(w)) {
-            uint32_t o[4];
-            draw(r, SSE_TAG_DIAG, p, o);
+            uint32_t o[2];
+            draw_diag(r, p, o);
             uint32_t b = sse_op_bond(w);
             double num = beta_nb * bond_weight(m, b, sse_op_in(w), sse_op_in(w));
             double den = (double)(M - r->n + 1u);

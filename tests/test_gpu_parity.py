@@ -8,10 +8,10 @@ import _lattices as lat
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(oracle, edges, gamma, h, cutoff, cap, seed, R, waves=0, state=None):
+def make_pair(oracle, edges, gamma, h, cutoff, cap, seed, R, waves=0, state=None, k=0, cfg_flags=0, uf_limit=0):
     import isingmontecarlo_amd as im
     g = im.QmcIsingGraph(edges, gamma, h, cutoff, seed, state=state, nreplicas=R, capacity=cap,
-                         waves_per_replica=waves)
+                         waves_per_replica=waves, slots_per_lane=k, cfg_flags=cfg_flags, lds_uf_ids_limit=uf_limit)
     e, j = lat.split(edges)
     m = oracle.Model(g.nvars, e, j, gamma, h)
     reps = [oracle.Replica(m, cap, cutoff, seed, r, None if state is None else state) for r in range(R)]
@@ -38,21 +38,27 @@ CASES = [
     ("villain4", lat.two_d_periodic(4), 1.0, 0.0, 2.0),
     ("ferro6_long", lat.one_d_periodic(6, -1.0), 1.0, 0.3, 2.0),
     ("ferro8x8", lat.two_d_ferro(8), 1.0, 0.0, 4.0),
+    ("ring5_randmag", [((0, 1), 0.7), ((1, 2), -1.3), ((2, 3), 1.9), ((3, 4), -0.6), ((4, 0), 1.1)], 1.2, -0.4, 1.5),
 ]
 
 
-@pytest.mark.parametrize("waves", [1, 2, 8])
+GEOMS = [(1, 1, 0), (1, 4, 0), (4, 2, 0), (4, 4, 1), (8, 1, 0), (8, 4, 0), (8, 4, 1), (16, 4, 0), (16, 2, 1)]
+
+
+@pytest.mark.parametrize("waves", [1, 4, 8])
 @pytest.mark.parametrize("name,edges,gamma,h,beta", CASES)
 def test_init_state_matches(oracle, name, edges, gamma, h, beta, waves):
     g, m, reps = make_pair(oracle, edges, gamma, h, 16, 4096, 77, 3, waves)
     assert_same(g, reps, "init")
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+@pytest.mark.parametrize("waves,k,cfgf", GEOMS)
 @pytest.mark.parametrize("name,edges,gamma,h,beta", CASES)
-def test_primitives_step_by_step(oracle, name, edges, gamma, h, beta, waves):
+def test_primitives_step_by_step(oracle, name, edges, gamma, h, beta, waves, k, cfgf):
     R = 4
-    g, m, reps = make_pair(oracle, edges, gamma, h, 16, 8192, 1234, R, waves)
+    g, m, reps = make_pair(oracle, edges, gamma, h, 16, 8192, 1234, R, waves, k=k, cfg_flags=cfgf)
+    info = g.launch_info()
+    assert info["waves_per_replica"] == waves and info["slots_per_lane"] == k and info["lds_edge_table"] == (cfgf == 0)
     for it in range(12):
         g.single_diagonal_step(beta)
         for rep in reps:
@@ -78,6 +84,8 @@ def test_primitives_step_by_step(oracle, name, edges, gamma, h, beta, waves):
 def test_fused_timesteps(oracle, name, edges, gamma, h, beta, flags):
     R = 5
     g, m, reps = make_pair(oracle, edges, gamma, h, 8, 8192, 99, R)
+    if flags & 1:
+        g.set_steps_per_launch(7)  # sampling phase must carry across launches
     g.run(40, beta, sampling_freq=3, flags=flags)
     for rep in reps:
         rep.timesteps(40, beta, 3, flags)
@@ -88,10 +96,11 @@ def test_fused_timesteps(oracle, name, edges, gamma, h, beta, flags):
     assert g.verify().all()
 
 
-def test_loop_update_matches(oracle):
+@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (1, 1, 1), (16, 2, 0)])
+def test_loop_update_matches(oracle, waves, k, cfgf):
     edges = lat.two_d_periodic(4)
     R = 6
-    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 8, 4096, 5, R)
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 8, 4096, 5, R, waves=waves, k=k, cfg_flags=cfgf)
     g.run(20, 2.0)
     for rep in reps:
         rep.timesteps(20, 2.0, 1, 0)
@@ -103,26 +112,28 @@ def test_loop_update_matches(oracle):
     assert g.verify().all()
 
 
-def test_medium_lattice_many_replicas(oracle):
+@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (16, 4, 0), (8, 4, 1)])
+def test_medium_lattice_many_replicas(oracle, waves, k, cfgf):
     edges = lat.two_d_ferro(16)
     R = 16
-    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 256, 1 << 15, 2024, R)
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 256, 1 << 15, 2024, R, waves=waves, k=k, cfg_flags=cfgf)
     g.run(30, 4.0)
     oracle.batch_timesteps(reps, 30, [4.0] * R)
     assert_same(g, reps, "16x16")
     assert g.verify().all()
 
 
-def test_union_find_global_fallback(oracle):
-    # tiny LDS union-find capacity is impossible to request directly; instead use a system whose
-    # segment count exceeds what 160 KB of LDS can hold: 64x64 at beta=8 with 16 waves.
-    edges = lat.two_d_ferro(48)
-    R = 2
-    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 2304, 1 << 18, 31, R, waves=8)
+@pytest.mark.parametrize("waves,k", [(8, 4), (4, 1), (16, 4)])
+def test_union_find_global_fallback(oracle, waves, k):
+    # cap the LDS union-find so that N + (transverse ops) exceeds it: the HBM union-find path must agree
+    edges = lat.two_d_ferro(12)
+    R = 3
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 144, 1 << 14, 31, R, waves=waves, k=k, uf_limit=400)
     info = g.launch_info()
-    g.run(20, 8.0)
-    oracle.batch_timesteps(reps, 20, [8.0] * R)
-    assert_same(g, reps, "48x48")
+    assert info["lds_uf_ids"] == 400
+    g.run(25, 4.0)
+    oracle.batch_timesteps(reps, 25, [4.0] * R)
+    assert_same(g, reps, "12x12 global union-find")
     # make sure this case really left the LDS path: N + (transverse ops) must exceed the LDS id capacity
     bonds = (reps[0].ops() >> 4).astype(np.int64) - 1
     ntrans = int(((bonds >= len(edges)) & (bonds < len(edges) + g.nvars)).sum())

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-pass timing of the sweep at equilibrium (HIP events through the C ABI). Dev tool, GPU only."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import _lattices as lat
+import isingmontecarlo_amd as im
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--L", type=int, default=32); ap.add_argument("--beta", type=float, default=16.0)
+ap.add_argument("--replicas", type=int, default=1024); ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--equilibrate", type=int, default=60); ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--k", type=int, default=0); ap.add_argument("--nolds", action="store_true")
+a = ap.parse_args()
+L, R, beta = a.L, a.replicas, a.beta
+n_est = beta * 5.2 * L * L
+cap = 1 << int(np.ceil(np.log2(2.0 * n_est + 4 * L * L)))
+g = im.QmcIsingGraph(lat.two_d_ferro(L), 1.0, 0.0, L * L, 1234, nreplicas=R, capacity=cap, waves_per_replica=a.waves, slots_per_lane=a.k, cfg_flags=1 if a.nolds else 0)
+g.run(a.equilibrate, beta)
+print("launch", g.launch_info(), "mean n", g.get_n().mean(), "mean M", g.get_cutoff().mean())
+def t(fn, name):
+    ms = []
+    for _ in range(a.reps):
+        fn(); ms.append(g.last_kernel_ms()[0])
+    print(f"{name:28s} {np.median(ms):8.3f} ms  (min {min(ms):.3f})")
+t(lambda: g.single_diagonal_step(beta), "diagonal")
+t(lambda: g.single_cluster_step(flip_free=False), "cluster")
+t(lambda: g.loop_update(), "loop")
+t(lambda: g.flip_free_spins(), "free (with touch scan)")
+t(lambda: g.run(1, beta), "timestep diag+cluster+free")
+t(lambda: g.run(1, beta, flags=im.FLAG_LOOP), "timestep +loop")
+t(lambda: g.run(1, beta, flags=im.FLAG_HEATBATH), "timestep heatbath")
+t(lambda: g.run(10, beta), "10 timesteps fused")
