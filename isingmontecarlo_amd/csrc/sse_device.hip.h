@@ -117,31 +117,39 @@ __device__ __forceinline__ double bond_weight(const Bd &b, uint32_t in, uint32_t
 
 // ---------------------------------------------------------------------------------------------
 // LDS carve (dynamic shared memory).  All sizes in u32 words.
+// Every LDS access below indexes this one array directly so that the compiler always emits ds_*
+// instructions (pointers held in structs decay to the generic address space and become flat_* ops,
+// which are slower and make s_waitcnt on LDS data also wait for the in-flight HBM prefetches).
+extern __shared__ __align__(16) uint32_t lds_raw[];
+#define LDSW(off, i) lds_raw[(off) + (i)]
+#define LDSI(off, i) (reinterpret_cast<int &>(lds_raw[(off) + (i)]))
+
 template <int W>
-struct Lds {
-    uint32_t *state;   // [nwords]      p=0 spin state
-    uint32_t *scopy;   // [W][nwords]   spin-state copies (XOR scan)
-    uint32_t *touch;   // [nwords]      variables touched by any op
-    int *tot;          // [2][W]        per-wave totals (double buffered by round parity)
-    uint32_t *chg;     // [2][W]
-    uint32_t *misc;    // [16]
-    uint32_t *edges;   // [E]           compact edge table (CL mode only)
-    uint32_t *cur;     // [W][N]        latest-cut copies (MAX scan)
-    uint32_t *frozen;  // [ufwords]     bit per id: segment holds a longitudinal op
-    uint32_t *froot;   // [ufwords]     bit per id: root is frozen
-    uint32_t *parent;  // [ufcap]
-    __device__ void carve(uint32_t *base, uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges) {
-        state = base; base += nwords;
-        scopy = base; base += W * nwords;
-        touch = base; base += nwords;
-        tot = (int *)base; base += 2 * W;
-        chg = base; base += 2 * W;
-        misc = base; base += 16;
-        edges = base; base += ledges;
-        cur = base; base += (size_t)W * N;
-        frozen = base; base += (ufcap + 31) / 32;
-        froot = base; base += (ufcap + 31) / 32;
-        parent = base;
+struct Lds {           // word offsets into lds_raw
+    uint32_t o_state;  // [nwords]      p=0 spin state
+    uint32_t o_scopy;  // [W][nwords]   spin-state copies (XOR scan)
+    uint32_t o_touch;  // [nwords]      variables touched by any op
+    uint32_t o_tot;    // [2][W]        per-wave totals (double buffered by round parity)
+    uint32_t o_chg;    // [2][W]
+    uint32_t o_misc;   // [16]
+    uint32_t o_edges;  // [E]           compact edge table (CL mode only)
+    uint32_t o_cur;    // [W][N]        latest-cut copies (MAX scan)
+    uint32_t o_frozen; // [ufwords]     bit per id: segment holds a longitudinal op
+    uint32_t o_froot;  // [ufwords]     bit per id: root is frozen
+    uint32_t o_parent; // [ufcap]
+    __device__ __forceinline__ void carve(uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges) {
+        uint32_t base = 0;
+        o_state = base; base += nwords;
+        o_scopy = base; base += W * nwords;
+        o_touch = base; base += nwords;
+        o_tot = base; base += 2 * W;
+        o_chg = base; base += 2 * W;
+        o_misc = base; base += 16;
+        o_edges = base; base += ledges;
+        o_cur = base; base += W * N;
+        o_frozen = base; base += (ufcap + 31) / 32;
+        o_froot = base; base += (ufcap + 31) / 32;
+        o_parent = base;
     }
 };
 enum { MISC_NCLUST = 0, MISC_ANYFROZEN = 1, MISC_LOOP_A = 2, MISC_LOOP_B = 3, MISC_LOOP_C = 4, MISC_LOOP_D = 5 };
@@ -151,7 +159,7 @@ __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, ui
     Bd d;
     if constexpr (CL) {
         if (b < B.E) {
-            const uint32_t e = L.edges[b];
+            const uint32_t e = LDSW(L.o_edges, b);
             d.a = e & SSE_CE_VAR_MASK; d.c = (e >> 15) & SSE_CE_VAR_MASK;
             d.kp = SSE_BOND_TWO_SITE | (((e >> 30) & 1u) << 2);
             d.w = B.uniformJ ? B.wJ : B.edge_w[b];
@@ -182,7 +190,7 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int 
 // (qmc_traits/diagonal.rs:114-135) with metropolis_single_diagonal_update (:142-191), or the heat-bath
 // rule (qmc_traits/heatbath.rs:149-209) when HB.
 template <int W, int K, bool CL, bool HB>
-__device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rng &rng, double beta, uint32_t M,
+__device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double beta, uint32_t M,
                               int &n_io, int &ntrans_io, uint32_t &gr) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -190,9 +198,9 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
     uint32_t *ops = B.ops + (size_t)r * B.cap;
     const double beta_nb = beta * (double)B.Nb;
     const double hb_bw = beta * B.wtot;
-    uint32_t *mycopy = L.scopy + wave * nwords;
+    const uint32_t o_mycopy = L.o_scopy + wave * nwords;
 
-    for (uint32_t i = tid; i < nwords * W; i += NT) L.scopy[i] = L.state[i % nwords];
+    for (uint32_t i = tid; i < nwords * W; i += NT) LDSW(L.o_scopy, i) = LDSW(L.o_state, i % nwords);
     __syncthreads();
 
     const uint32_t ntiles = (M + NT * K - 1) / (NT * K);
@@ -210,8 +218,8 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
         const uint32_t x = sse_op_in(wnext[j]) ^ sse_op_out(wnext[j]);
         if (x) {
             const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wnext[j]));
-            if (x & 1u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (d.a >> 5)], 1u << (d.a & 31));
-            if (x & 2u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (d.c >> 5)], 1u << (d.c & 31));
+            if (x & 1u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.a >> 5)), 1u << (d.a & 31));
+            if (x & 2u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.c >> 5)), 1u << (d.c & 31));
         }
     }
     __syncthreads();
@@ -271,8 +279,8 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
             // spin reads for insertion candidates: own copy xor earlier events of this sub-round
             uint32_t sa = 0, sc = 0;
             if (is_empty) {
-                sa = (mycopy[d.a >> 5] >> (d.a & 31)) & 1u;
-                if (d.c != SSE_NO_VAR) sc = (mycopy[d.c >> 5] >> (d.c & 31)) & 1u;
+                sa = (LDSW(o_mycopy, d.a >> 5) >> (d.a & 31)) & 1u;
+                if (d.c != SSE_NO_VAR) sc = (LDSW(o_mycopy, d.c >> 5) >> (d.c & 31)) & 1u;
             }
             const uint64_t ev0 = __ballot((xb[j] & 1u) != 0u);
             const uint64_t ev1 = __ballot((xb[j] & 2u) != 0u);
@@ -292,8 +300,8 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
             }
             // this sub-round's events become visible to the wave's later sub-rounds
             if (K > 1 && (ev0 | ev1)) {
-                if (xb[j] & 1u) atomicXor(&mycopy[d.a >> 5], 1u << (d.a & 31));
-                if (xb[j] & 2u) atomicXor(&mycopy[d.c >> 5], 1u << (d.c & 31));
+                if (xb[j] & 1u) atomicXor(&LDSW(o_mycopy, d.a >> 5), 1u << (d.a & 31));
+                if (xb[j] & 2u) atomicXor(&LDSW(o_mycopy, d.c >> 5), 1u << (d.c & 31));
             }
             sub[j] = sa | (sc << 1);
             cand[j] = 0; num[j] = 0.0; u[j] = 0.0;
@@ -338,7 +346,7 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
             }
             const uint64_t cm = __ballot(changed);
             const int buf = gr & 1;
-            if (lane == 0) { L.tot[buf * W + wave] = wtot; L.chg[buf * W + wave] = cm != 0ull; }
+            if (lane == 0) { LDSI(L.o_tot, buf * W + wave) = wtot; LDSW(L.o_chg, buf * W + wave) = cm != 0ull; }
             __syncthreads();
             if (first) {
                 first = false;
@@ -347,8 +355,8 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
                     const int wend = (K > 1) ? wave : wave + 1;
-                    if (xb[j] & 1u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&L.scopy[w2 * nwords + (evA[j] >> 5)], 1u << (evA[j] & 31));
-                    if (xb[j] & 2u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&L.scopy[w2 * nwords + (evC[j] >> 5)], 1u << (evC[j] & 31));
+                    if (xb[j] & 1u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (evA[j] >> 5)), 1u << (evA[j] & 31));
+                    if (xb[j] & 2u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (evC[j] >> 5)), 1u << (evC[j] & 31));
                 }
                 // events of the next tile -> copies of later waves (visible after the next barrier)
 #pragma unroll
@@ -356,18 +364,18 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
                     const uint32_t xn = sse_op_in(wnext[j]) ^ sse_op_out(wnext[j]);
                     if (xn) {
                         const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wnext[j]));
-                        if (xn & 1u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (d.a >> 5)], 1u << (d.a & 31));
-                        if (xn & 2u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&L.scopy[w2 * nwords + (d.c >> 5)], 1u << (d.c & 31));
+                        if (xn & 1u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.a >> 5)), 1u << (d.a & 31));
+                        if (xn & 2u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.c >> 5)), 1u << (d.c & 31));
                     }
                 }
             }
             int base = 0; tot_all = 0; uint32_t anychg = 0;
 #pragma unroll
             for (int w2 = 0; w2 < W; ++w2) {
-                const int t = L.tot[buf * W + w2];
+                const int t = LDSI(L.o_tot, buf * W + w2);
                 if (w2 < wave) base += t;
                 tot_all += t;
-                anychg |= L.chg[buf * W + w2];
+                anychg |= LDSW(L.o_chg, buf * W + w2);
             }
             gr++;
             if (dec_prev[0] != 2 && !anychg) break;
@@ -392,50 +400,72 @@ __device__ void diagonal_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
     }
     // per-wave transverse deltas -> block total
     __syncthreads();
-    if (lane == 0) L.tot[wave] = ntrans;
+    if (lane == 0) LDSI(L.o_tot, wave) = ntrans;
     __syncthreads();
     int dt = 0;
 #pragma unroll
-    for (int w2 = 0; w2 < W; ++w2) dt += L.tot[w2];
+    for (int w2 = 0; w2 < W; ++w2) dt += LDSI(L.o_tot, w2);
     __syncthreads();
     ntrans_io += dt;
     n_io = n_start;
 }
 
 // ---------------------------------------------------------------------------------------------
+// Union-find storage: LDS (fast path) or the per-replica HBM scratch (when N + #cuts exceeds the LDS
+// capacity).  The accessor keeps the address space static so that the LDS path compiles to ds_* ops.
+template <bool G>
+struct UFA {
+    uint32_t *gparent, *gfrozen, *gfroot; // HBM arrays (G)
+    uint32_t o_parent, o_frozen, o_froot; // lds_raw offsets (!G)
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { if constexpr (G) return gparent[i]; else return LDSW(o_parent, i); }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { if constexpr (G) gparent[i] = v; else LDSW(o_parent, i) = v; }
+    __device__ __forceinline__ uint32_t cas(uint32_t i, uint32_t cmp, uint32_t v) const {
+        if constexpr (G) return atomicCAS(&gparent[i], cmp, v); else return atomicCAS(&LDSW(o_parent, i), cmp, v);
+    }
+    __device__ __forceinline__ void frozen_or(uint32_t w, uint32_t bits) const { if constexpr (G) atomicOr(&gfrozen[w], bits); else atomicOr(&LDSW(o_frozen, w), bits); }
+    __device__ __forceinline__ void froot_or(uint32_t w, uint32_t bits) const { if constexpr (G) atomicOr(&gfroot[w], bits); else atomicOr(&LDSW(o_froot, w), bits); }
+    __device__ __forceinline__ uint32_t frozen_get(uint32_t w) const { if constexpr (G) return gfrozen[w]; else return LDSW(o_frozen, w); }
+    __device__ __forceinline__ uint32_t froot_get(uint32_t w) const { if constexpr (G) return gfroot[w]; else return LDSW(o_froot, w); }
+    __device__ __forceinline__ void bits_clear(uint32_t w) const {
+        if constexpr (G) { gfrozen[w] = 0u; gfroot[w] = 0u; } else { LDSW(o_frozen, w) = 0u; LDSW(o_froot, w) = 0u; }
+    }
+};
+
 // Lock-free union-find with smallest-id roots (canonical cluster labels).
-__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
-    uint32_t p = parent[x];
+template <bool G>
+__device__ __forceinline__ uint32_t uf_find(const UFA<G> &uf, uint32_t x) {
+    uint32_t p = uf.get(x);
     while (p != x) {
-        const uint32_t g = parent[p];
-        if (g != p) parent[x] = g; // path halving; benign race (always an ancestor)
+        const uint32_t g = uf.get(p);
+        if (g != p) uf.set(x, g); // path halving; benign race (always an ancestor)
         x = p;
         p = g;
     }
     return x;
 }
-__device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
+template <bool G>
+__device__ __forceinline__ void uf_union(const UFA<G> &uf, uint32_t a, uint32_t b) {
     for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+        a = uf_find(uf, a);
+        b = uf_find(uf, b);
         if (a == b) return;
         if (a > b) { const uint32_t t = a; a = b; b = t; }
-        if (atomicCAS(&parent[b], b, a) == b) return;
+        if (uf.cas(b, b, a) == b) return;
     }
 }
 
 // Segment scan shared by cluster build and apply.  For the tile's ops it yields, per slot, the segment ids
 // of its legs (seg_a for var a, seg_c for var c, id_own for a cut's outgoing segment).
 // Segment ids: [0,N) = worldline part containing p=0 (placeholder), N+k = segment opened by the k-th cut.
-template <int W, int K, bool CL, bool APPLY>
-__device__ void cluster_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t M, uint32_t *parent,
-                             uint32_t *frozen, uint32_t &gr, uint32_t &ncuts_out) {
+template <int W, int K, bool CL, bool APPLY, bool G>
+__device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<G> &uf,
+                                             uint32_t &gr, uint32_t &ncuts_out) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t N = B.N;
     uint32_t *ops = B.ops + (size_t)r * B.cap;
-    uint32_t *mycur = L.cur + (size_t)wave * N;
-    for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) L.cur[i] = 0u;
+    const uint32_t o_mycur = L.o_cur + wave * N;
+    for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) LDSW(L.o_cur, i) = 0u;
     __syncthreads();
     const uint32_t ntiles = (M + NT * K - 1) / (NT * K);
     uint32_t cutbase = 0;
@@ -474,16 +504,16 @@ __device__ void cluster_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t 
             wcuts += popc64(cutmask[j]);
         }
         const int buf = gr & 1;
-        if (lane == 0) L.tot[buf * W + wave] = wcuts;
+        if (lane == 0) LDSI(L.o_tot, buf * W + wave) = wcuts;
         __syncthreads(); // (A)
         gr++;
         uint32_t wbase = 0, total = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)L.tot[buf * W + w2]; if (w2 < wave) wbase += t; total += t; }
+        for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2); if (w2 < wave) wbase += t; total += t; }
         // previous tile's cuts become visible to earlier waves (everyone finished reading that tile)
 #pragma unroll
         for (int j = 0; j < K; ++j)
-            if (pend_id[j]) for (int w2 = 0; w2 < wave; ++w2) atomicMax(&L.cur[(size_t)w2 * N + pend_v[j]], pend_id[j]);
+            if (pend_id[j]) for (int w2 = 0; w2 < wave; ++w2) atomicMax(&LDSW(L.o_cur, w2 * N + pend_v[j]), pend_id[j]);
         uint32_t id_own[K];
         uint32_t first_id[K];
         {
@@ -495,8 +525,8 @@ __device__ void cluster_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t 
                 run += popc64(cutmask[j]);
                 const bool iscut = (cutmask[j] >> lane) & 1ull;
                 if (iscut) {
-                    if (!APPLY) parent[id_own[j]] = id_own[j];
-                    for (int w2 = wave + 1; w2 < W; ++w2) atomicMax(&L.cur[(size_t)w2 * N + va[j]], id_own[j]);
+                    if (!APPLY) uf.set(id_own[j], id_own[j]);
+                    for (int w2 = wave + 1; w2 < W; ++w2) atomicMax(&LDSW(L.o_cur, w2 * N + va[j]), id_own[j]);
                 }
                 pend_v[j] = va[j];
                 pend_id[j] = iscut ? id_own[j] : 0u;
@@ -509,8 +539,8 @@ __device__ void cluster_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t 
             const bool iscut = (cutmask[j] >> lane) & 1ull;
             uint32_t seg_a = 0, seg_c = 0;
             if (nonempty) {
-                seg_a = mycur[va[j]];
-                if (vc[j] != SSE_NO_VAR) seg_c = mycur[vc[j]];
+                seg_a = LDSW(o_mycur, va[j]);
+                if (vc[j] != SSE_NO_VAR) seg_c = LDSW(o_mycur, vc[j]);
             }
             {
                 uint64_t m = cutmask[j];
@@ -524,27 +554,27 @@ __device__ void cluster_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t 
                 }
             }
             // this sub-round's cuts become visible to the wave's later sub-rounds (ids grow with p)
-            if (iscut) atomicMax(&mycur[va[j]], id_own[j]);
+            if (iscut) atomicMax(&LDSW(o_mycur, va[j]), id_own[j]);
             if (nonempty) {
                 if (seg_a == 0u) seg_a = va[j];
                 if (vc[j] != SSE_NO_VAR && seg_c == 0u) seg_c = vc[j];
                 if (!APPLY) {
-                    atomicOr(&L.touch[va[j] >> 5], 1u << (va[j] & 31));
+                    atomicOr(&LDSW(L.o_touch, va[j] >> 5), 1u << (va[j] & 31));
                     if (kind[j] == SSE_BOND_TWO_SITE) {
-                        atomicOr(&L.touch[vc[j] >> 5], 1u << (vc[j] & 31));
-                        uf_union(parent, seg_a, seg_c);
+                        atomicOr(&LDSW(L.o_touch, vc[j] >> 5), 1u << (vc[j] & 31));
+                        uf_union(uf, seg_a, seg_c);
                     } else if (kind[j] == SSE_BOND_LONGITUDINAL) {
-                        atomicOr(&frozen[seg_a >> 5], 1u << (seg_a & 31));
+                        uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
                     }
                 } else {
                     const uint32_t wd = word[j];
                     uint32_t in = sse_op_in(wd), out = sse_op_out(wd);
-                    const uint32_t fa = parent[seg_a];
+                    const uint32_t fa = uf.get(seg_a);
                     if (iscut) {
                         in ^= fa;
-                        out ^= parent[id_own[j]];
+                        out ^= uf.get(id_own[j]);
                     } else if (kind[j] == SSE_BOND_TWO_SITE) {
-                        const uint32_t f2 = fa | (parent[seg_c] << 1);
+                        const uint32_t f2 = fa | (uf.get(seg_c) << 1);
                         in ^= f2; out ^= f2;
                     } else {
                         in ^= fa; out ^= fa;
@@ -559,7 +589,7 @@ __device__ void cluster_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t 
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < K; ++j)
-        if (pend_id[j]) for (int w2 = 0; w2 < wave; ++w2) atomicMax(&L.cur[(size_t)w2 * N + pend_v[j]], pend_id[j]);
+        if (pend_id[j]) for (int w2 = 0; w2 < wave; ++w2) atomicMax(&LDSW(L.o_cur, w2 * N + pend_v[j]), pend_id[j]);
     __syncthreads();
     ncuts_out = cutbase;
 }
@@ -567,54 +597,53 @@ __device__ void cluster_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t 
 // Cluster update.  Reference: ClusterUpdater::flip_each_cluster_rng (qmc_traits/cluster.rs:36-172) with the
 // longitudinal weight function of qmc_ising.rs:759-775.  Returns the number of clusters.
 template <int W, int K, bool CL, bool UF_GLOBAL>
-__device__ uint32_t cluster_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rng &rng, double prob, uint32_t M,
-                                 int n, int ntrans, uint32_t &gr) {
+__device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double prob,
+                                                 uint32_t M, int n, int ntrans, uint32_t &gr) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t N = B.N, nwords = B.nwords;
-    uint32_t *parent, *frozen, *froot;
-    if constexpr (UF_GLOBAL) {
+    UFA<UF_GLOBAL> uf;
+    {
         const size_t ids = (size_t)N + B.cap;
-        parent = B.uf_scratch + (size_t)r * (ids + 2 * ((ids + 31) / 32));
-        frozen = parent + ids;
-        froot = frozen + (ids + 31) / 32;
-    } else {
-        parent = L.parent; frozen = L.frozen; froot = L.froot;
+        uf.gparent = B.uf_scratch + (size_t)r * (ids + 2 * ((ids + 31) / 32));
+        uf.gfrozen = uf.gparent + ids;
+        uf.gfroot = uf.gfrozen + (ids + 31) / 32;
+        uf.o_parent = L.o_parent; uf.o_frozen = L.o_frozen; uf.o_froot = L.o_froot;
     }
-    for (uint32_t i = tid; i < nwords; i += NT) L.touch[i] = 0u;
-    if (tid == 0) { L.misc[MISC_NCLUST] = 0u; L.misc[MISC_ANYFROZEN] = 0u; }
+    for (uint32_t i = tid; i < nwords; i += NT) LDSW(L.o_touch, i) = 0u;
+    if (tid == 0) { LDSW(L.o_misc, MISC_NCLUST) = 0u; LDSW(L.o_misc, MISC_ANYFROZEN) = 0u; }
     if (n == 0) { __syncthreads(); return 0u; } // cluster.rs:46-48
     const uint32_t S = N + (uint32_t)ntrans; // ids: N placeholders + one per cut (transverse op)
-    for (uint32_t i = tid; i < N; i += NT) parent[i] = i;
-    for (uint32_t i = tid; i < (S + 31) / 32; i += NT) { frozen[i] = 0u; froot[i] = 0u; }
+    for (uint32_t i = tid; i < N; i += NT) uf.set(i, i);
+    for (uint32_t i = tid; i < (S + 31) / 32; i += NT) uf.bits_clear(i);
     __syncthreads();
     // ---- build: label legs with segment ids, union through non-boundary ops ----
     uint32_t ncuts = 0;
-    cluster_scan<W, K, CL, false>(B, L, r, M, parent, frozen, gr, ncuts);
+    cluster_scan<W, K, CL, false, UF_GLOBAL>(B, L, r, M, uf, gr, ncuts);
     // wrap-around: the part of worldline v before its first cut continues the segment of its last cut.
     // A wave applies its own cuts to its own copy and to every other wave's copy, so after the scan the
     // last cut on v is the maximum over all copies.
     for (uint32_t v = tid; v < N; v += NT) {
         uint32_t last = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) { const uint32_t x = L.cur[(size_t)w2 * N + v]; last = x > last ? x : last; }
-        if (last) uf_union(parent, v, last);
+        for (int w2 = 0; w2 < W; ++w2) { const uint32_t x = LDSW(L.o_cur, w2 * N + v); last = x > last ? x : last; }
+        if (last) uf_union(uf, v, last);
     }
     __syncthreads();
     // ---- flatten: parent[i] := exact root (no union runs any more), frozen marks move to roots ----
     for (uint32_t i = tid; i < S; i += NT) {
-        const uint32_t root = uf_find(parent, i);
-        parent[i] = root;
-        if ((frozen[i >> 5] >> (i & 31)) & 1u) { atomicOr(&froot[root >> 5], 1u << (root & 31)); L.misc[MISC_ANYFROZEN] = 1u; }
+        const uint32_t root = uf_find(uf, i);
+        uf.set(i, root);
+        if ((uf.frozen_get(i >> 5) >> (i & 31)) & 1u) { uf.froot_or(root >> 5, 1u << (root & 31)); LDSW(L.o_misc, MISC_ANYFROZEN) = 1u; }
     }
     __syncthreads();
     // ---- coins: each thread reads only parent[i] of its own ids, so parent[i] := flip bit in place ----
     uint32_t myclusters = 0;
     const bool nocuts = (ncuts == 0u);
-    const uint32_t anyfrozen = L.misc[MISC_ANYFROZEN];
+    const uint32_t anyfrozen = LDSW(L.o_misc, MISC_ANYFROZEN);
     for (uint32_t i = tid; i < S; i += NT) {
-        const uint32_t root = parent[i];
-        const bool touched = i >= N || ((L.touch[i >> 5] >> (i & 31)) & 1u);
+        const uint32_t root = uf.get(i);
+        const bool touched = i >= N || ((LDSW(L.o_touch, i >> 5) >> (i & 31)) & 1u);
         uint32_t f;
         if (nocuts) {
             // no cluster boundary anywhere: the whole graph is one cluster (cluster.rs:98-107), label 0
@@ -623,38 +652,38 @@ __device__ uint32_t cluster_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const
         } else {
             if (root == i && touched) myclusters++;
             const uint4 o = rng.draw(SSE_TAG_CLUSTER, root);
-            const uint32_t isfrozen = (froot[root >> 5] >> (root & 31)) & 1u;
+            const uint32_t isfrozen = (uf.froot_get(root >> 5) >> (root & 31)) & 1u;
             f = (!isfrozen && u01(o.x) < prob) ? 1u : 0u;
         }
-        parent[i] = f;
+        uf.set(i, f);
     }
     {
         uint32_t c = myclusters;
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-        if (lane == 0 && c) atomicAdd(&L.misc[MISC_NCLUST], c);
+        if (lane == 0 && c) atomicAdd(&LDSW(L.o_misc, MISC_NCLUST), c);
     }
     __syncthreads();
     // ---- apply (cluster.rs:139-167) ----
     uint32_t ncuts2 = 0;
-    cluster_scan<W, K, CL, true>(B, L, r, M, parent, frozen, gr, ncuts2);
+    cluster_scan<W, K, CL, true, UF_GLOBAL>(B, L, r, M, uf, gr, ncuts2);
     // p=0 state follows the placeholder segment of each touched variable
     for (uint32_t i = tid; i < nwords; i += NT) {
         uint32_t x = 0;
-        const uint32_t t = L.touch[i];
-        for (uint32_t j = 0; j < 32 && i * 32 + j < N; ++j) x |= (parent[i * 32 + j] & 1u) << j;
-        L.state[i] ^= (x & t);
+        const uint32_t t = LDSW(L.o_touch, i);
+        for (uint32_t j = 0; j < 32 && i * 32 + j < N; ++j) x |= (uf.get(i * 32 + j) & 1u) << j;
+        LDSW(L.o_state, i) ^= (x & t);
     }
     __syncthreads();
-    return nocuts ? 1u : L.misc[MISC_NCLUST];
+    return nocuts ? 1u : LDSW(L.o_misc, MISC_NCLUST);
 }
 
 // touched-variable scan for launches that flip free spins without a preceding cluster pass
 template <int W, bool CL>
-__device__ void touch_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t M) {
+__device__ __forceinline__ void touch_scan(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
     const uint32_t *ops = B.ops + (size_t)r * B.cap;
-    for (uint32_t i = tid; i < B.nwords; i += NT) L.touch[i] = 0u;
+    for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_touch, i) = 0u;
     __syncthreads();
     for (uint32_t p0 = 0; p0 < M; p0 += 4 * NT) {
         uint32_t wd[4];
@@ -664,8 +693,8 @@ __device__ void touch_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t M)
         for (int j = 0; j < 4; ++j) {
             if (!wd[j]) continue;
             const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
-            atomicOr(&L.touch[d.a >> 5], 1u << (d.a & 31));
-            if (d.c != SSE_NO_VAR) atomicOr(&L.touch[d.c >> 5], 1u << (d.c & 31));
+            atomicOr(&LDSW(L.o_touch, d.a >> 5), 1u << (d.a & 31));
+            if (d.c != SSE_NO_VAR) atomicOr(&LDSW(L.o_touch, d.c >> 5), 1u << (d.c & 31));
         }
     }
     __syncthreads();
@@ -673,18 +702,18 @@ __device__ void touch_scan(const DevBatch &B, Lds<W> &L, uint32_t r, uint32_t M)
 
 // qmc_ising.rs:780-784 / qmc_runner.rs:241-255
 template <int W>
-__device__ void free_spin_pass(const DevBatch &B, Lds<W> &L, const Rng &rng) {
+__device__ __forceinline__ void free_spin_pass(const DevBatch &B, const Lds<W> &L, const Rng &rng) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < B.nwords; i += NT) {
-        const uint32_t t = L.touch[i];
-        uint32_t s = L.state[i];
+        const uint32_t t = LDSW(L.o_touch, i);
+        uint32_t s = LDSW(L.o_state, i);
         for (uint32_t j = 0; j < 32 && i * 32 + j < B.N; ++j)
             if (!((t >> j) & 1u)) {
                 const uint4 o = rng.draw(SSE_TAG_FREE, i * 32 + j);
                 s = (s & ~(1u << j)) | ((o.x >> 31) << j);
             }
-        L.state[i] = s;
+        LDSW(L.o_state, i) = s;
     }
     __syncthreads();
 }
@@ -697,7 +726,7 @@ __device__ void free_spin_pass(const DevBatch &B, Lds<W> &L, const Rng &rng) {
 //   get_next/previous_p_for_rel_var (:51-54)     -> tile-wise search along the worldline direction
 // Returns the number of vertices visited.
 template <int W, bool CL>
-__device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rng &rng, uint32_t M, int n, uint32_t &gr,
+__device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, uint32_t M, int n, uint32_t &gr,
                               uint32_t &err) {
     constexpr int NT = W * 64;
     constexpr int U = 4; // independent loads in flight per thread during searches
@@ -708,7 +737,7 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
     const uint32_t nth = __umulhi(o0.x, (uint32_t)n);
     // ---- start vertex: the nth occupied slot in p order (chunks of U*NT slots, wave-major inside) ----
     uint32_t cbase = 0;
-    if (tid == 0) L.misc[MISC_LOOP_A] = 0xFFFFFFFFu;
+    if (tid == 0) LDSW(L.o_misc, MISC_LOOP_A) = 0xFFFFFFFFu;
     __syncthreads();
     for (uint32_t q0 = 0; q0 < M; q0 += U * NT) {
         uint32_t wd[U];
@@ -719,24 +748,24 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
 #pragma unroll
         for (int j = 0; j < U; ++j) { occ[j] = __ballot(wd[j] != 0u); cnt += popc64(occ[j]); }
         const int buf = gr & 1;
-        if (lane == 0) L.tot[buf * W + wave] = cnt;
+        if (lane == 0) LDSI(L.o_tot, buf * W + wave) = cnt;
         __syncthreads();
         gr++;
         uint32_t wbase = 0, total = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)L.tot[buf * W + w2]; if (w2 < wave) wbase += t; total += t; }
+        for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2); if (w2 < wave) wbase += t; total += t; }
         uint32_t run = cbase + wbase;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const uint32_t myrank = run + popc64(occ[j] & lanemask_lt(lane));
-            if (wd[j] != 0u && myrank == nth) L.misc[MISC_LOOP_A] = q0 + (uint32_t)(wave * 64 * U + j * 64 + lane);
+            if (wd[j] != 0u && myrank == nth) LDSW(L.o_misc, MISC_LOOP_A) = q0 + (uint32_t)(wave * 64 * U + j * 64 + lane);
             run += popc64(occ[j]);
         }
         cbase += total;
         if (cbase > nth) break;
     }
     __syncthreads();
-    const uint32_t p0 = L.misc[MISC_LOOP_A];
+    const uint32_t p0 = LDSW(L.o_misc, MISC_LOOP_A);
     if (p0 == 0xFFFFFFFFu) { err = 2u; return 0u; } // n inconsistent with the op-string
     uint32_t rel0, side0;
     {
@@ -775,16 +804,16 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
             ops[p] = (word & ~0xFu) | in_e | (out_e << SSE_OP_OUT_SHIFT);
             const bool closed = (p == p0 && xrel == rel0 && xside == side0);
             const uint32_t var = xrel == 0u ? d.a : d.c;
-            L.misc[MISC_LOOP_A] = closed ? 1u : 0u;
-            L.misc[MISC_LOOP_B] = var;
-            L.misc[MISC_LOOP_C] = xside | (xrel << 1) | ((((xside == 1u ? out_e : in_e) >> xrel) & 1u) << 2);
-            L.misc[MISC_LOOP_D] = 0xFFFFFFFFu; // best distance
+            LDSW(L.o_misc, MISC_LOOP_A) = closed ? 1u : 0u;
+            LDSW(L.o_misc, MISC_LOOP_B) = var;
+            LDSW(L.o_misc, MISC_LOOP_C) = xside | (xrel << 1) | ((((xside == 1u ? out_e : in_e) >> xrel) & 1u) << 2);
+            LDSW(L.o_misc, MISC_LOOP_D) = 0xFFFFFFFFu; // best distance
         }
         __syncthreads();
         visited++;
-        if (L.misc[MISC_LOOP_A]) { finished = true; break; }
-        const uint32_t var = L.misc[MISC_LOOP_B];
-        const uint32_t info = L.misc[MISC_LOOP_C];
+        if (LDSW(L.o_misc, MISC_LOOP_A)) { finished = true; break; }
+        const uint32_t var = LDSW(L.o_misc, MISC_LOOP_B);
+        const uint32_t info = LDSW(L.o_misc, MISC_LOOP_C);
         const uint32_t xside = info & 1u, newbit = (info >> 2) & 1u;
         const bool forward = xside == 1u;
         // ---- search the next op on worldline `var`, distance 1..M (distance M = the op itself) ----
@@ -812,9 +841,9 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
                 const uint64_t mm = __ballot(match);
                 if (mm) best = d0 + (uint32_t)(j * NT + wave * 64) + (uint32_t)(__ffsll((long long)mm) - 1);
             }
-            if (best != 0xFFFFFFFFu && lane == 0) atomicMin(&L.misc[MISC_LOOP_D], best);
+            if (best != 0xFFFFFFFFu && lane == 0) atomicMin(&LDSW(L.o_misc, MISC_LOOP_D), best);
             __syncthreads();
-            found = L.misc[MISC_LOOP_D];
+            found = LDSW(L.o_misc, MISC_LOOP_D);
             __syncthreads();
             if (found != 0xFFFFFFFFu) break;
         }
@@ -826,7 +855,7 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
         const uint32_t nrel = dq.a == var ? 0u : 1u;
         if (wrapped && tid == 0) { // directed_loop.rs:276-288
             const uint32_t wi = var >> 5, bi = var & 31;
-            L.state[wi] = (L.state[wi] & ~(1u << bi)) | (newbit << bi);
+            LDSW(L.o_state, wi) = (LDSW(L.o_state, wi) & ~(1u << bi)) | (newbit << bi);
         }
         const uint32_t nside = xside ^ 1u;
         if (q == p0 && nrel == rel0 && nside == side0) { finished = true; break; } // :293
@@ -845,15 +874,14 @@ __device__ uint32_t loop_pass(const DevBatch &B, Lds<W> &L, uint32_t r, const Rn
 // two apart; the code is identical.
 template <int W, int K, bool CL, int PHASE>
 __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) {
-    extern __shared__ __align__(16) uint32_t lds_raw[];
     constexpr int NT = W * 64;
     Lds<W> L;
-    L.carve(lds_raw, B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u);
+    L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u);
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
-    for (uint32_t i = tid; i < B.nwords; i += NT) L.state[i] = B.state[(size_t)r * B.nwords + i];
+    for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_state, i) = B.state[(size_t)r * B.nwords + i];
     if constexpr (CL)
-        for (uint32_t i = tid; i < B.E; i += NT) L.edges[i] = B.edges_compact[i];
+        for (uint32_t i = tid; i < B.E; i += NT) LDSW(L.o_edges, i) = B.edges_compact[i];
     __syncthreads();
     int n = (int)B.n[r], ntrans = (int)B.ntrans[r];
     uint32_t M = B.cutoff[r], err = B.err[r], gr = 0, last_out = 0;
@@ -894,20 +922,20 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
             epoch++;
         }
         if (A.sampling_freq && (A.step0 + step + 1) % A.sampling_freq == 0) {
-            if (tid == 0) L.misc[MISC_LOOP_A] = 0u;
+            if (tid == 0) LDSW(L.o_misc, MISC_LOOP_A) = 0u;
             __syncthreads();
             uint32_t up = 0;
-            for (uint32_t i = tid; i < B.nwords; i += NT) up += __popc(L.state[i]);
+            for (uint32_t i = tid; i < B.nwords; i += NT) up += __popc(LDSW(L.o_state, i));
             for (int off = 32; off > 0; off >>= 1) up += __shfl_down(up, off);
-            if ((tid & 63) == 0 && up) atomicAdd(&L.misc[MISC_LOOP_A], up);
+            if ((tid & 63) == 0 && up) atomicAdd(&LDSW(L.o_misc, MISC_LOOP_A), up);
             __syncthreads();
-            const long long mag = 2ll * (long long)L.misc[MISC_LOOP_A] - (long long)B.N;
+            const long long mag = 2ll * (long long)LDSW(L.o_misc, MISC_LOOP_A) - (long long)B.N;
             a0 += (uint64_t)n; a1 += 1; a2 += (uint64_t)(mag < 0 ? -mag : mag); a3 += (uint64_t)(mag * mag); a6 += (uint64_t)ntrans;
             __syncthreads();
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < B.nwords; i += NT) B.state[(size_t)r * B.nwords + i] = L.state[i];
+    for (uint32_t i = tid; i < B.nwords; i += NT) B.state[(size_t)r * B.nwords + i] = LDSW(L.o_state, i);
     if (tid == 0) {
         B.n[r] = (uint32_t)n; B.ntrans[r] = (uint32_t)ntrans; B.cutoff[r] = M; B.err[r] = err; B.epoch[r] = epoch;
         if (A.out_u32) A.out_u32[r] = last_out;
