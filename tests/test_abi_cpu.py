@@ -1,0 +1,90 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/isingmc_hip.h declares, and fails loudly (no CPU fallback) when no HIP device exists."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "isingmc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(isingmc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    import isingmontecarlo_amd as im
+    lib = im.load_library()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"libisingmc_hip.so does not export {n}"
+        assert n in im.SYMBOLS, f"python binding misses {n}"
+    assert set(im.SYMBOLS) == set(names)
+
+
+def test_config_struct_layout_matches_header():
+    import isingmontecarlo_amd as im
+    # 4 u32, 2 pointers, 2 doubles, 2 u32, u64, u32, i32, pointer, 4 u32 -> 96 bytes on LP64
+    assert C.sizeof(im._Config) == 96
+    assert im._Config.seed.offset == 56 and im._Config.init_state.offset == 72
+
+
+def test_no_device_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import isingmontecarlo_amd as im
+    with pytest.raises(im.IsingMcError) as ei:
+        im.QmcIsingGraph([((0, 1), 1.0)], 1.0, 0.0, 4, 1)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_create_rejects_bad_arguments():
+    import isingmontecarlo_amd as im
+    lib = im.load_library()
+    h = C.c_void_p()
+    cfg = im._Config(struct_size=4)  # wrong size
+    assert lib.isingmc_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"struct_size" in lib.isingmc_last_error(None)
+    ed = np.array([0, 5], dtype=np.uint32); js = np.array([1.0])
+    cfg = im._Config(struct_size=C.sizeof(im._Config), nreplicas=1, nvars=2, nedges=1,
+                     edges=ed.ctypes.data_as(C.POINTER(C.c_uint32)), J=js.ctypes.data_as(C.POINTER(C.c_double)),
+                     transverse=1.0, capacity=8, cutoff0=4, device=-1)
+    assert lib.isingmc_create(C.byref(cfg), C.byref(h)) == -1  # edge endpoint out of range
+    cfg.nvars = 6; cfg.cutoff0 = 9
+    assert lib.isingmc_create(C.byref(cfg), C.byref(h)) == -1  # cutoff0 > capacity
+
+
+def test_null_handle_calls_do_not_crash():
+    import isingmontecarlo_amd as im
+    lib = im.load_library()
+    assert lib.isingmc_timesteps(None, 1, None, 1, 0) == -1
+    assert lib.isingmc_get_n(None, None) == -1
+    assert lib.isingmc_num_bonds(None) == 0
+    lib.isingmc_destroy(None)
+
+
+def test_op_word_helpers_round_trip():
+    import isingmontecarlo_amd as im
+    for bond in (0, 1, 4095, (1 << 28) - 3):
+        for i in range(4):
+            for o in range(4):
+                w = im.op_make(bond, i, o)
+                assert w != 0 and im.op_fields(w) == (bond, i, o)
+    assert im.op_fields(0) is None
+
+
+def test_lattice_builders_match_reference_ordering():
+    import _lattices as lat
+    e = lat.two_d_periodic(4)
+    # benches/end_to_end.rs:12-30: 16 right bonds (J=-1) then 16 down bonds (+1 on even columns)
+    assert len(e) == 32 and all(j == -1.0 for _, j in e[:16])
+    assert e[0][0] == (0, 1) and e[16][0] == (0, 4) and e[16][1] == 1.0
+    (a, b), j = e[16 + 4]  # i=1, j=0 -> odd column
+    assert (a, b) == (1, 5) and j == -1.0
+    assert lat.one_d_periodic(16)[-1] == ((15, 0), 1.0)

@@ -1,0 +1,163 @@
+"""CPU tests: the oracle against the committed golden vectors and the reference's own invariants.
+
+* Philox4x32-10 against the Random123 known-answer vectors (Salmon et al., SC'11, kat_vectors).
+* Energies / magnetisations against exact diagonalisation (tests/golden/ed_tfim.json, generator
+  tests/golden/make_ed_golden.py) within 4 sigma of the Monte-Carlo error (the 1-sigma parity claim is
+  checked at higher statistics in DESIGN.md; 4 sigma keeps this suite deterministic-enough and fast).
+* The reference's structural tests (tests/longitudinal_crash.rs, tests/cluster_test.rs,
+  tests/convert_test.rs): verify() after many steps on the same graphs and toggles.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _lattices as lat
+import _oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_philox_known_answers():
+    import ctypes as C
+    L = O.lib()
+
+    def ph(ctr, key):
+        c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+        L.ora_philox4x32_10(c, k, o)
+        return list(o)
+    assert ph([0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert ph([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+with open(os.path.join(HERE, "golden", "ed_tfim.json")) as f:
+    ED = json.load(f)
+ED_CASES = [(c, r) for c in ED for r in c["results"]]
+
+
+@pytest.mark.parametrize("flags", [0, O.FLAG_HEATBATH, O.FLAG_LOOP])
+@pytest.mark.parametrize("case,res", ED_CASES, ids=[f"{c['name']}-b{r['beta']}" for c, r in ED_CASES])
+def test_oracle_matches_exact_diagonalisation(case, res, flags):
+    if flags and case["nvars"] > 8:
+        pytest.skip("variants are checked on the small systems")
+    m = O.Model(case["nvars"], case["edges"], case["J"], case["gamma"], case["h"])
+    beta, R = res["beta"], 16
+    reps = [O.Replica(m, 4096, case["nvars"], 20240 + flags, r) for r in range(R)]
+    O.batch_timesteps(reps, 1000, [beta] * R, 1, flags)
+    for r in reps:
+        r.reset_accumulators()
+    O.batch_timesteps(reps, 8000, [beta] * R, 1, flags)
+    acc = np.array([r.accumulators() for r in reps], dtype=np.float64)
+    assert all(r.verify() for r in reps)
+    n = case["nvars"]
+    obs = {
+        "energy": -(acc[:, 0] / acc[:, 1]) / beta + m.offset,
+        "abs_m": acc[:, 2] / acc[:, 1] / n,
+        "m2": acc[:, 3] / acc[:, 1] / n ** 2,
+        "sx": acc[:, 6] / acc[:, 1] / (beta * case["gamma"] * n) - 1.0,
+    }
+    for k, x in obs.items():
+        mu, se = x.mean(), x.std(ddof=1) / np.sqrt(R)
+        assert abs(mu - res[k]) < 4.0 * se + 1e-9, f"{case['name']} beta={beta} {k}: {mu} +- {se} vs exact {res[k]}"
+
+
+def two_unit_cell():
+    return [((0, 1), -1.0), ((1, 2), 1.0), ((2, 3), 1.0), ((3, 0), 1.0), ((1, 7), 1.0),
+            ((4, 5), -1.0), ((5, 6), 1.0), ((6, 7), 1.0), ((7, 4), 1.0)]
+
+
+# tests/longitudinal_crash.rs:39-178 — graph, Gamma, h, cutoff; 16 seeds x 1000 timesteps at beta = 1, all-down start
+CRASH = [
+    ("single_bond", [((0, 1), 1.0)], 1.0, 1.0, 2),
+    ("villain3", lat.two_d_periodic(3), 0.1, 0.1, 9),
+    ("villain4", lat.two_d_periodic(4), 0.1, 0.1, 16),
+    ("two_unit_cell", two_unit_cell(), 0.1, 0.1, 8),
+    ("two_unit_cell_noh", two_unit_cell(), 1.0, 0.0, 8),
+]
+
+
+@pytest.mark.parametrize("flags", [0, O.FLAG_HEATBATH, O.FLAG_LOOP])
+@pytest.mark.parametrize("name,edges,gamma,h,cutoff", CRASH, ids=[c[0] for c in CRASH])
+def test_reference_crash_graphs_stay_consistent(name, edges, gamma, h, cutoff, flags):
+    e, j = lat.split(edges)
+    nvars = max(max(a, b) for a, b in e) + 1
+    m = O.Model(nvars, e, j, gamma, h)
+    for seed in range(16):
+        r = O.Replica(m, 4096, cutoff, seed, 0, [0] * nvars)
+        r.timesteps(1000, 1.0, 1, flags)
+        assert r.verify(), f"{name} seed {seed}"
+        assert r.cutoff >= r.n
+
+
+def test_convert_test_equivalence():
+    # tests/convert_test.rs: QmcIsingGraph::timestep and Qmc::timestep (into_qmc, loop updates off) must
+    # leave identical states; with counter-based RNG both drivers are the same sequence of primitives.
+    edges = lat.one_d_periodic(3)
+    e, j = lat.split(edges)
+    m = O.Model(3, e, j, 1.0, 0.0)
+    a = O.Replica(m, 256, 3, 1234, 0, [1, 1, 1])
+    b = O.Replica(m, 256, 3, 1234, 0, [1, 1, 1])
+    for _ in range(10):
+        a.timestep(1.0, 0)  # QmcIsingGraph::timestep
+        b.diagonal_update(1.0)  # Qmc::timestep = diagonal_update; [loop]; cluster_update; flip_free_bits
+        want = b.n + b.n // 2
+        if want > b.cutoff:
+            b.set_cutoff(want)
+        b.cluster_update(0.5)
+        b.flip_free_spins()
+    assert np.array_equal(a.state(), b.state())
+    assert np.array_equal(a.ops(), b.ops())
+
+
+def test_cluster_fixtures_from_reference():
+    # tests/cluster_test.rs:6-75: constant single-site ops only; every op side pair is its own boundary.
+    edges = [((0, 1), 1.0)]
+    m = O.Model(2, [[0, 1]], [1.0], 1.0, 0.0)
+    tb = lambda v: 1 + v  # transverse bond of variable v: E + v
+    for words, nclusters in [
+        ([O.op_make(tb(0), 0, 0)], 1),                                   # single_cluster_test
+        ([O.op_make(tb(0), 0, 0), O.op_make(tb(0), 0, 0)], 2),          # simple_cluster_test
+        ([O.op_make(tb(0), 0, 0), O.op_make(tb(0), 0, 0), O.op_make(tb(1), 0, 0), O.op_make(tb(1), 0, 0)], 4),
+    ]:
+        for seed in range(8):
+            r = O.Replica(m, 16, 4, seed, 0, [0, 0])
+            r.set_ops(words)
+            assert r.verify()
+            assert r.cluster_update(0.5) == nclusters
+            assert r.verify()
+
+
+def test_loop_fixture_bounces_on_ising_bonds():
+    # tests/check_loop_crash.rs uses an XX-like Hamiltonian; with Ising weights a two-site diagonal op has
+    # zero off-diagonal weight, so every loop through it must bounce and leave the string unchanged.
+    m = O.Model(3, [[0, 1], [1, 2]], [-1.0, -1.0], 1.0, 0.0)
+    words = [O.op_make(0, 0, 0), O.op_make(1, 0, 0)]
+    r = O.Replica(m, 16, 2, 0, 0, [0, 0, 0])
+    r.set_ops(words)
+    for _ in range(100):
+        assert r.loop_update() == 1
+    assert np.array_equal(r.ops(), np.array(words, dtype=np.uint32))
+    assert r.verify()
+
+
+def test_cutoff_only_grows_and_capacity_is_reported():
+    m = O.Model(2, [[0, 1]], [1.0], 1.0, 0.0)
+    r = O.Replica(m, 8, 2, 1, 0)
+    assert r.set_cutoff(4) == 0 and r.cutoff == 4
+    assert r.set_cutoff(3) == 0 and r.cutoff == 4  # fast_ops.rs:1258-1262
+    assert r.set_cutoff(9) != 0
+    assert r.timestep(50.0) != 0 or r.cutoff <= 8  # n + n/2 > capacity must be reported, not ignored
+
+
+def test_bond_counts_and_energy_offset():
+    edges = lat.one_d_periodic(4, -1.0)
+    e, j = lat.split(edges)
+    m = O.Model(4, e, j, 0.7, 0.25)
+    assert m.nbonds == 4 + 4 + 4
+    assert abs(m.offset - (4 * 1.0 + 4 * (0.7 + 0.25))) < 1e-12  # qmc_ising.rs:97-99
+    r = O.Replica(m, 512, 4, 3, 0)
+    r.timesteps(200, 2.0)
+    assert sum(r.bond_count(b) for b in range(m.nbonds)) == r.n
