@@ -124,6 +124,8 @@ int isingmc_set_stream(isingmc_batch *b, void *hip_stream);
 int isingmc_synchronize(isingmc_batch *b);
 /* HIP-event timing of the most recent isingmc_timesteps launch(es): total ms and number of kernel launches */
 int isingmc_last_kernel_ms(isingmc_batch *b, float *ms, uint32_t *launches);
+/* diagnostic builds (-DSSE_PHASE_TIMING) only: per-replica phase durations in 10-ns ticks, out[R][16]; zero otherwise */
+int isingmc_debug_phase_ticks(isingmc_batch *b, uint64_t *out, int reset);
 /* number of sweeps fused into one kernel launch by isingmc_timesteps (0 = all t steps in one launch) */
 int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
 /* build/launch configuration actually in use: out[0]=waves per replica, out[1]=dynamic LDS bytes,

@@ -67,6 +67,7 @@ SYMBOLS = {
     "isingmc_verify": (C.c_int, [_vp, _P(C.c_uint8)]),
     "isingmc_set_stream": (C.c_int, [_vp, _vp]),
     "isingmc_set_steps_per_launch": (C.c_int, [_vp, _u64]),
+    "isingmc_debug_phase_ticks": (C.c_int, [_vp, _P(_u64), C.c_int]),
     "isingmc_synchronize": (C.c_int, [_vp]),
     "isingmc_last_kernel_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
     "isingmc_get_launch_info": (C.c_int, [_vp, _P(_u32)]),
@@ -311,6 +312,11 @@ class QmcIsingGraph:
         self._check(self._lib.isingmc_get_launch_info(self._h, out))
         return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3],
                     slots_per_lane=out[4], lds_edge_table=bool(out[5]))
+
+    def debug_phase_ticks(self, reset=True):
+        out = np.zeros((self.nreplicas, 16), dtype=np.uint64)
+        self._check(self._lib.isingmc_debug_phase_ticks(self._h, _ptr(out, C.c_uint64), 1 if reset else 0))
+        return out
 
     def set_steps_per_launch(self, steps):
         self._check(self._lib.isingmc_set_steps_per_launch(self._h, int(steps)))

@@ -10,6 +10,8 @@ SOURCES = ["isingmc_hip.hip", "sweep_w1.hip", "sweep_w4.hip", "sweep_w8.hip", "s
 HEADERS = ["sse_device.hip.h", os.path.join("..", "..", "include", "isingmc_hip.h"),
            os.path.join("..", "..", "include", "sse_format.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+if os.environ.get("SSE_PHASE_TIMING"):  # diagnostic build: in-kernel phase stamps (never benchmarked)
+    FLAGS.append("-DSSE_PHASE_TIMING")
 
 
 def _stale():

@@ -78,10 +78,17 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
     const uint32_t *ops = B.ops + (size_t)r * B.cap;
     const uint32_t M = B.cutoff[r];
     bool good = true;
-    uint32_t count = 0, ntr = 0;
+    uint32_t count = 0, ntr = 0, ccn = 0, cctr = 0;
+    const uint32_t *chunks = B.chunks + (size_t)r * 2 * SSE_MAX_CHUNKS;
     for (uint32_t p = 0; p < B.cap; ++p) {
+        if (p % B.CH == 0 && p) { // per-chunk counters kept by the diagonal pass must match the op-string
+            const uint32_t c = p / B.CH - 1;
+            if (chunks[c] != ccn || chunks[SSE_MAX_CHUNKS + c] != cctr) good = false;
+            ccn = 0; cctr = 0;
+        }
         const uint32_t w = ops[p];
         if (!w) continue;
+        ccn++;
         if (p >= M) { good = false; break; }
         count++;
         const uint32_t b = sse_op_bond(w);
@@ -91,7 +98,7 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
         d.a = rec.a_info & SSE_VAR_MASK; d.c = rec.c; d.kp = rec.a_info >> SSE_INFO_SHIFT; d.w = rec.w;
         const uint32_t in = sse_op_in(w), out = sse_op_out(w);
         if (!(bond_weight(d, in, out) > 2.220446049250313e-16)) good = false;
-        if (bd_kind(d) == SSE_BOND_TRANSVERSE) ntr++;
+        if (bd_kind(d) == SSE_BOND_TRANSVERSE) { ntr++; cctr++; }
         const uint32_t a = d.a, c = d.c;
         if (((s[a >> 5] >> (a & 31)) & 1u) != (in & 1u)) good = false;
         s[a >> 5] = (s[a >> 5] & ~(1u << (a & 31))) | ((out & 1u) << (a & 31));
@@ -100,13 +107,17 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
             s[c >> 5] = (s[c >> 5] & ~(1u << (c & 31))) | (((out >> 1) & 1u) << (c & 31));
         } else if ((in | out) & 2u) good = false;
     }
+    if (good) { // last chunk
+        const uint32_t c = (B.cap - 1) / B.CH;
+        if (chunks[c] != ccn || chunks[SSE_MAX_CHUNKS + c] != cctr) good = false;
+    }
     for (uint32_t i = 0; i < B.nwords; ++i) if (s[i] != s0[i]) good = false;
     if (count != B.n[r] || ntr != B.ntrans[r]) good = false;
     ok[r] = good ? 1 : 0;
 }
 
 static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges) {
-    return (size_t)nwords * (W + 2) + 4 * W + 16 + ledges + (size_t)W * N;
+    return (size_t)nwords * (W + 2) + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + 64 * W + ledges + ((size_t)W * N + 1) / 2;
 }
 
 static int check_errors(isingmc_batch *b) {
@@ -250,8 +261,16 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (fixed + 64 > total_words) { b->err = "model too large: per-variable scan tables do not fit in LDS"; return fail(ISINGMC_ENOTIMPL); }
     const size_t remaining = total_words - fixed;
     size_t ufcap = (remaining - 2) * 32 / 34;
-    const size_t ids_max = (size_t)D.N + D.cap;
+    const size_t ids_max = (size_t)W * D.N + D.cap;
     if (ufcap > ids_max) ufcap = ids_max;
+    // chunk grid for the per-chunk counters: <= SSE_MAX_CHUNKS chunks of CH slots, CH a multiple of 256
+    D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
+    D.nchunks = (D.cap + D.CH - 1) / D.CH;
+    // the cluster scan keeps 16-bit cut ranks per wave range: a range holds at most ceil(chunks/W)*CH slots
+    if ((size_t)((D.nchunks + W - 1) / W) * D.CH >= 65535u) {
+        b->err = "capacity per wave exceeds 65534 slots: raise waves_per_replica (16) or lower capacity";
+        return fail(ISINGMC_ENOTIMPL);
+    }
     if (cfg->lds_uf_ids_limit && ufcap > cfg->lds_uf_ids_limit) ufcap = cfg->lds_uf_ids_limit;
     D.lds_ufcap = (uint32_t)ufcap;
     b->W = W; b->K = K; b->CL = CL ? 1u : 0u;
@@ -271,6 +290,8 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if ((rc = dalloc(b, &D.aux, D.R))) return fail(rc);
     if ((rc = dalloc(b, &D.epoch, D.R))) return fail(rc);
     if ((rc = dalloc(b, &D.acc, (size_t)D.R * 8))) return fail(rc);
+    if ((rc = dalloc(b, &D.chunks, (size_t)D.R * 2 * SSE_MAX_CHUNKS))) return fail(rc);
+    if ((rc = dalloc(b, &D.dbg, (size_t)D.R * 16))) return fail(rc);
     BondRec *dbonds = nullptr; double *dcum = nullptr;
     if ((rc = dalloc(b, &dbonds, D.Nb, false))) return fail(rc);
     if ((rc = dalloc(b, &dcum, D.Nb, false))) return fail(rc);
@@ -426,12 +447,18 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
     if (!b || (!words && nwords) || r >= b->dev.R) { if (b) b->err = "bad arguments to import_ops"; return ISINGMC_EINVAL; }
     if (nwords > b->dev.cap) { b->err = "op-string longer than capacity"; return ISINGMC_ECAPACITY; }
     uint32_t n = 0, ntr = 0;
+    std::vector<uint32_t> chunks(2 * SSE_MAX_CHUNKS, 0u);
     for (uint32_t p = 0; p < nwords; ++p) {
         if (!words[p]) continue;
         const uint32_t bond = sse_op_bond(words[p]);
         if (bond >= b->dev.Nb) { b->err = "op refers to a bond outside the model"; return ISINGMC_EINVAL; }
+        // Ising bonds: two-site and longitudinal ops have zero off-diagonal weight (qmc_ising.rs:863-888)
+        const uint32_t kind = (b->bonds_host[bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK;
+        if (kind != SSE_BOND_TRANSVERSE && sse_op_in(words[p]) != sse_op_out(words[p])) { b->err = "off-diagonal op on a diagonal-only bond (zero weight)"; return ISINGMC_EINVAL; }
+        if (b->bonds_host[bond].c == SSE_NO_VAR && ((sse_op_in(words[p]) | sse_op_out(words[p])) & 2u)) { b->err = "single-site op with second-variable bits set"; return ISINGMC_EINVAL; }
         n++;
-        if (((b->bonds_host[bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK) == SSE_BOND_TRANSVERSE) ntr++;
+        chunks[p / b->dev.CH]++;
+        if (((b->bonds_host[bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK) == SSE_BOND_TRANSVERSE) { ntr++; chunks[SSE_MAX_CHUNKS + p / b->dev.CH]++; }
     }
     HIP_TRY(b, hipSetDevice(b->device));
     uint32_t *dst = b->dev.ops + (size_t)r * b->dev.cap;
@@ -442,6 +469,7 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
     if (nwords > cur) HIP_TRY(b, hipMemcpy(b->dev.cutoff + r, &nwords, 4, hipMemcpyHostToDevice));
     HIP_TRY(b, hipMemcpy(b->dev.n + r, &n, 4, hipMemcpyHostToDevice));
     HIP_TRY(b, hipMemcpy(b->dev.ntrans + r, &ntr, 4, hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(b->dev.chunks + (size_t)r * 2 * SSE_MAX_CHUNKS, chunks.data(), sizeof(uint32_t) * chunks.size(), hipMemcpyHostToDevice));
     return ISINGMC_OK;
 }
 int isingmc_get_bond_count(isingmc_batch *b, uint32_t r, uint32_t bond, uint32_t *out) {
@@ -468,6 +496,13 @@ int isingmc_verify(isingmc_batch *b, uint8_t *ok) {
 int isingmc_set_stream(isingmc_batch *b, void *hip_stream) {
     if (!b) return ISINGMC_EINVAL;
     b->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return ISINGMC_OK;
+}
+int isingmc_debug_phase_ticks(isingmc_batch *b, uint64_t *out /*[R][16]*/, int reset) {
+    if (!b || !out) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipMemcpy(out, b->dev.dbg, sizeof(uint64_t) * 16 * b->dev.R, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(b, hipMemset(b->dev.dbg, 0, sizeof(uint64_t) * 16 * b->dev.R));
     return ISINGMC_OK;
 }
 int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps) {

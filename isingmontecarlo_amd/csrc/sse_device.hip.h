@@ -32,6 +32,7 @@ struct BondRec {       // 16 B, one dwordx4 load (general table, any N / E)
 // compact edge entry (staged in LDS when N <= 32768): a | c << 15 | prefers_aligned << 30
 #define SSE_CE_VAR_MASK 0x7FFFu
 #define SSE_CE_MAX_VARS 32768u
+#define SSE_MAX_CHUNKS 128u
 
 struct DevBatch {
     uint32_t R, N, E, Nb, cap, nwords;
@@ -47,10 +48,21 @@ struct DevBatch {
     double wtot;
     double wJ, gamma, wh; // uniform 2|J| (if uniformJ), Gamma, 2|h|
     uint32_t uniformJ, hpos;
-    uint32_t *uf_scratch; // [R][N+cap (+bit arrays)] union-find fallback in HBM
+    uint32_t *chunks;     // [R][2*SSE_MAX_CHUNKS]: per chunk of CH slots: occupied count, transverse-op count
+    uint32_t CH, nchunks; // chunk size (multiple of 256 slots) and number of chunks covering cap
+    uint32_t *uf_scratch; // [R][W*N+cap (+bit arrays)] union-find fallback in HBM
     uint32_t seed_lo, seed_hi, replica_offset;
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
+    unsigned long long *dbg; // [R][16] phase durations in 10-ns ticks (diagnostic builds only, -DSSE_PHASE_TIMING)
 };
+
+#ifdef SSE_PHASE_TIMING
+#define SSE_STAMP(slot) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); B.dbg[(size_t)r * 16 + (slot)] += t_ - dbg_t0; dbg_t0 = t_; } } while (0)
+#define SSE_STAMP_INIT unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime()
+#else
+#define SSE_STAMP(slot) do { } while (0)
+#define SSE_STAMP_INIT do { } while (0)
+#endif
 
 // which primitives a launch runs per step
 #define SSE_DO_DIAG 1u
@@ -105,14 +117,13 @@ struct Bd {
 };
 __device__ __forceinline__ uint32_t bd_kind(const Bd &b) { return b.kp & SSE_BOND_KIND_MASK; }
 
-// matrix element of the shifted bond operator (reference: src/sse/qmc_ising.rs:863-888)
+// matrix element of the shifted bond operator (reference: src/sse/qmc_ising.rs:863-888); straight-line code
 __device__ __forceinline__ double bond_weight(const Bd &b, uint32_t in, uint32_t out) {
     const uint32_t kind = b.kp & SSE_BOND_KIND_MASK, pref = (b.kp >> 2) & 1u;
-    if (kind == SSE_BOND_TRANSVERSE) return b.w;
-    if (in != out) return 0.0;
-    const uint32_t sat = (kind == SSE_BOND_TWO_SITE) ? (uint32_t)(((in & 1u) == ((in >> 1) & 1u)) == (pref != 0u))
-                                                     : (uint32_t)((in & 1u) == pref);
-    return sat ? b.w : 0.0;
+    const uint32_t aligned = ((in ^ (in >> 1)) & 1u) ^ 1u;
+    const uint32_t sat = (kind == SSE_BOND_TWO_SITE) ? (uint32_t)(aligned == pref) : (uint32_t)((in & 1u) == pref);
+    const bool ok = (kind == SSE_BOND_TRANSVERSE) | ((in == out) & (sat != 0u));
+    return ok ? b.w : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -123,6 +134,11 @@ __device__ __forceinline__ double bond_weight(const Bd &b, uint32_t in, uint32_t
 extern __shared__ __align__(16) uint32_t lds_raw[];
 #define LDSW(off, i) lds_raw[(off) + (i)]
 #define LDSI(off, i) (reinterpret_cast<int &>(lds_raw[(off) + (i)]))
+#define LDSH(off, i) (reinterpret_cast<uint16_t *>(lds_raw)[2u * (off) + (i)]) // 16-bit element i of the array at word offset off
+// volatile forms for tables that OTHER lanes of the same wave write between two reads of one lane (the C++
+// memory model would let the compiler reuse the first value); LDS operations of a wave execute in order.
+#define LDSHV(off, i) (reinterpret_cast<volatile uint16_t *>(lds_raw)[2u * (off) + (i)])
+#define LDSWV(off, i) (reinterpret_cast<volatile uint32_t *>(lds_raw)[(off) + (i)])
 
 template <int W>
 struct Lds {           // word offsets into lds_raw
@@ -132,8 +148,11 @@ struct Lds {           // word offsets into lds_raw
     uint32_t o_tot;    // [2][W]        per-wave totals (double buffered by round parity)
     uint32_t o_chg;    // [2][W]
     uint32_t o_misc;   // [16]
+    uint32_t o_chn;    // [SSE_MAX_CHUNKS] occupied slots per chunk
+    uint32_t o_chtr;   // [SSE_MAX_CHUNKS] transverse ops per chunk
+    uint32_t o_cutlane; // [W][64]      per wave: lane of the k-th cut of the current sub-round
     uint32_t o_edges;  // [E]           compact edge table (CL mode only)
-    uint32_t o_cur;    // [W][N]        latest-cut copies (MAX scan)
+    uint32_t o_cur;    // [W][N] u16    per wave: rank+1 (within the wave's range) of the latest cut on each variable
     uint32_t o_frozen; // [ufwords]     bit per id: segment holds a longitudinal op
     uint32_t o_froot;  // [ufwords]     bit per id: root is frozen
     uint32_t o_parent; // [ufcap]
@@ -145,8 +164,11 @@ struct Lds {           // word offsets into lds_raw
         o_tot = base; base += 2 * W;
         o_chg = base; base += 2 * W;
         o_misc = base; base += 16;
+        o_chn = base; base += SSE_MAX_CHUNKS;
+        o_chtr = base; base += SSE_MAX_CHUNKS;
+        o_cutlane = base; base += W * 64;
         o_edges = base; base += ledges;
-        o_cur = base; base += W * N;
+        o_cur = base; base += (W * N + 1) / 2;
         o_frozen = base; base += (ufcap + 31) / 32;
         o_froot = base; base += (ufcap + 31) / 32;
         o_parent = base;
@@ -158,16 +180,17 @@ template <bool CL, int W>
 __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, uint32_t b) {
     Bd d;
     if constexpr (CL) {
-        if (b < B.E) {
-            const uint32_t e = LDSW(L.o_edges, b);
-            d.a = e & SSE_CE_VAR_MASK; d.c = (e >> 15) & SSE_CE_VAR_MASK;
-            d.kp = SSE_BOND_TWO_SITE | (((e >> 30) & 1u) << 2);
-            d.w = B.uniformJ ? B.wJ : B.edge_w[b];
-        } else if (b < B.E + B.N) {
-            d.a = b - B.E; d.c = SSE_NO_VAR; d.kp = SSE_BOND_TRANSVERSE; d.w = B.gamma;
-        } else {
-            d.a = b - B.E - B.N; d.c = SSE_NO_VAR; d.kp = SSE_BOND_LONGITUDINAL | (B.hpos << 2); d.w = B.wh;
-        }
+        // straight-line: one LDS read with a safe index, then selects
+        const bool two = b < B.E;
+        const uint32_t e = LDSW(L.o_edges, two ? b : 0u);
+        const uint32_t s1 = b - B.E;
+        const bool tr = s1 < B.N;
+        d.a = two ? (e & SSE_CE_VAR_MASK) : (tr ? s1 : s1 - B.N);
+        d.c = two ? ((e >> 15) & SSE_CE_VAR_MASK) : SSE_NO_VAR;
+        d.kp = two ? (SSE_BOND_TWO_SITE | (((e >> 30) & 1u) << 2))
+                   : (tr ? SSE_BOND_TRANSVERSE : (SSE_BOND_LONGITUDINAL | (B.hpos << 2)));
+        const double w2 = B.uniformJ ? B.wJ : B.edge_w[two ? b : 0u];
+        d.w = two ? w2 : (tr ? B.gamma : B.wh);
     } else {
         const uint4 q = *reinterpret_cast<const uint4 *>(B.bonds + b);
         d.a = q.x & SSE_VAR_MASK; d.c = q.y; d.kp = q.x >> SSE_INFO_SHIFT;
@@ -215,11 +238,10 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const uint32_t x = sse_op_in(wnext[j]) ^ sse_op_out(wnext[j]);
+        const uint32_t x = (sse_op_in(wnext[j]) ^ sse_op_out(wnext[j])) & 1u;
         if (x) {
             const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wnext[j]));
-            if (x & 1u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.a >> 5)), 1u << (d.a & 31));
-            if (x & 2u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.c >> 5)), 1u << (d.c & 31));
+            for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.a >> 5)), 1u << (d.a & 31));
         }
     }
     __syncthreads();
@@ -239,7 +261,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             for (int j = 0; j < K; ++j) wnext[j] = 0u;
         }
 
-        uint32_t bsel[K], sub[K], evA[K], evC[K], xb[K];
+        uint32_t bsel[K], sub[K], evA[K], xb[K];
         double num[K], u[K];
         int cand[K]; // +1 insertion candidate, -1 removal candidate, 0 none
         bool tr[K];
@@ -262,57 +284,54 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 const bool hi = (K == 1) ? ((p & 64u) != 0u) : ((j & 1) != 0);
                 r0 = hi ? rnd.z : rnd.x; r1 = hi ? rnd.w : rnd.y;
             }
-            uint32_t b = 0;
-            if (wd) b = sse_op_bond(wd);
-            else if (HB) {
-                if (is_empty) {
+            uint32_t b;
+            if (HB) {
+                b = 0;
+                if (wd) b = sse_op_bond(wd);
+                else if (is_empty) {
                     const double c = u01(r2) * B.wtot;
                     uint32_t lo = 0, hi2 = B.Nb;
                     while (lo < hi2) { const uint32_t mid = lo + ((hi2 - lo) >> 1); if (B.cumw[mid] < c) lo = mid + 1; else hi2 = mid; }
                     b = lo < B.Nb ? lo : B.Nb - 1;
                 }
-            } else b = __umulhi(r0, B.Nb);
-            const Bd d = decode_bond<CL, W>(B, L, b);
-            bsel[j] = b;
-            evA[j] = d.a; evC[j] = d.c;
-            tr[j] = bd_kind(d) == SSE_BOND_TRANSVERSE;
-            // spin reads for insertion candidates: own copy xor earlier events of this sub-round
-            uint32_t sa = 0, sc = 0;
-            if (is_empty) {
-                sa = (LDSW(o_mycopy, d.a >> 5) >> (d.a & 31)) & 1u;
-                if (d.c != SSE_NO_VAR) sc = (LDSW(o_mycopy, d.c >> 5) >> (d.c & 31)) & 1u;
+            } else {
+                b = wd ? sse_op_bond(wd) : __umulhi(r0, B.Nb);
             }
-            const uint64_t ev0 = __ballot((xb[j] & 1u) != 0u);
-            const uint64_t ev1 = __ballot((xb[j] & 2u) != 0u);
+            const Bd d = decode_bond<CL, W>(B, L, b);
+            const uint32_t va = d.a;
+            const bool two = d.c != SSE_NO_VAR;
+            const uint32_t vc = two ? d.c : va;
+            bsel[j] = b;
+            evA[j] = va;
+            tr[j] = bd_kind(d) == SSE_BOND_TRANSVERSE;
+            // spin reads (unconditional, safe indices): own copy xor earlier off-diagonal events of this
+            // sub-round.  Ising bonds: only single-site ops can be off-diagonal (bit 0 of in^out).
+            uint32_t sa = (LDSW(o_mycopy, va >> 5) >> (va & 31)) & 1u;
+            uint32_t sc = two ? (LDSW(o_mycopy, vc >> 5) >> (vc & 31)) & 1u : 0u;
+            const bool isev = (xb[j] & 1u) != 0u;
+            const uint64_t ev0 = __ballot(isev);
             uint64_t m = ev0;
             while (m) {
                 const int Ls = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const uint32_t vL = __builtin_amdgcn_readlane(d.a, Ls);
-                if (lane > Ls) { sa ^= (uint32_t)(d.a == vL); sc ^= (uint32_t)(d.c == vL); }
-            }
-            m = ev1;
-            while (m) {
-                const int Ls = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const uint32_t vL = __builtin_amdgcn_readlane(d.c, Ls);
-                if (lane > Ls) { sa ^= (uint32_t)(d.a == vL); sc ^= (uint32_t)(d.c == vL); }
+                const uint32_t vL = __builtin_amdgcn_readlane(va, Ls);
+                const bool later = lane > Ls;
+                sa ^= (uint32_t)(later & (va == vL));
+                sc ^= (uint32_t)(later & two & (vc == vL));
             }
             // this sub-round's events become visible to the wave's later sub-rounds
-            if (K > 1 && (ev0 | ev1)) {
-                if (xb[j] & 1u) atomicXor(&LDSW(o_mycopy, d.a >> 5), 1u << (d.a & 31));
-                if (xb[j] & 2u) atomicXor(&LDSW(o_mycopy, d.c >> 5), 1u << (d.c & 31));
-            }
+            if (K > 1 && ev0 && isev) atomicXor(&LDSW(o_mycopy, va >> 5), 1u << (va & 31));
             sub[j] = sa | (sc << 1);
-            cand[j] = 0; num[j] = 0.0; u[j] = 0.0;
-            if (is_empty) {
-                const double w = bond_weight(d, sub[j], sub[j]);
-                if (HB) { cand[j] = (u01(r1) * d.w < w) ? 1 : 0; u[j] = u01(r0); }
-                else { num[j] = beta_nb * w; cand[j] = w > 0.0 ? 1 : 0; u[j] = u01(r1); }
-            } else if (is_diag) {
-                cand[j] = -1;
-                if (HB) u[j] = u01(r0);
-                else { num[j] = beta_nb * bond_weight(d, sse_op_in(wd), sse_op_in(wd)); u[j] = u01(r1); }
+            const double w_ins = bond_weight(d, sub[j], sub[j]);
+            const double w_rem = bond_weight(d, sse_op_in(wd), sse_op_in(wd));
+            if (HB) {
+                cand[j] = is_empty ? ((u01(r1) * d.w < w_ins) ? 1 : 0) : (is_diag ? -1 : 0);
+                num[j] = 0.0;
+                u[j] = u01(r0);
+            } else {
+                cand[j] = is_empty ? (w_ins > 0.0 ? 1 : 0) : (is_diag ? -1 : 0);
+                num[j] = beta_nb * (is_empty ? w_ins : w_rem);
+                u[j] = u01(r1);
             }
         }
 
@@ -356,16 +375,14 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 for (int j = 0; j < K; ++j) {
                     const int wend = (K > 1) ? wave : wave + 1;
                     if (xb[j] & 1u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (evA[j] >> 5)), 1u << (evA[j] & 31));
-                    if (xb[j] & 2u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (evC[j] >> 5)), 1u << (evC[j] & 31));
                 }
                 // events of the next tile -> copies of later waves (visible after the next barrier)
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
-                    const uint32_t xn = sse_op_in(wnext[j]) ^ sse_op_out(wnext[j]);
+                    const uint32_t xn = (sse_op_in(wnext[j]) ^ sse_op_out(wnext[j])) & 1u;
                     if (xn) {
                         const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wnext[j]));
-                        if (xn & 1u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.a >> 5)), 1u << (d.a & 31));
-                        if (xn & 2u) for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.c >> 5)), 1u << (d.c & 31));
+                        for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.a >> 5)), 1u << (d.a & 31));
                     }
                 }
             }
@@ -394,7 +411,14 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
                 ops[p] = dec[j] > 0 ? sse_op_make(bsel[j], sub[j], sub[j]) : 0u;
             }
-            ntrans += popc64(__ballot(dec[j] > 0 && tr[j])) - popc64(__ballot(dec[j] < 0 && tr[j]));
+            const int dtr = popc64(__ballot(dec[j] > 0 && tr[j])) - popc64(__ballot(dec[j] < 0 && tr[j]));
+            const int dn = popc64(__ballot(dec[j] > 0)) - popc64(__ballot(dec[j] < 0));
+            ntrans += dtr;
+            if (lane == 0 && (dtr | dn)) { // a sub-round's 64 slots lie inside one chunk (CH is a multiple of 256)
+                const uint32_t ch = slot_of<W, K>(tile, wave, j, 0) / B.CH;
+                if (dn) atomicAdd(&LDSW(L.o_chn, ch), (uint32_t)dn);
+                if (dtr) atomicAdd(&LDSW(L.o_chtr, ch), (uint32_t)dtr);
+            }
         }
         n_start += tot_all;
     }
@@ -454,144 +478,117 @@ __device__ __forceinline__ void uf_union(const UFA<G> &uf, uint32_t a, uint32_t 
     }
 }
 
-// Segment scan shared by cluster build and apply.  For the tile's ops it yields, per slot, the segment ids
-// of its legs (seg_a for var a, seg_c for var c, id_own for a cut's outgoing segment).
-// Segment ids: [0,N) = worldline part containing p=0 (placeholder), N+k = segment opened by the k-th cut.
+// Segment scan shared by cluster build and apply.  BARRIER-FREE: wave w owns a contiguous range of chunks of
+// the op-string and scans it alone, in p order, with its own copy of the "latest cut per variable" table.
+// Segment ids (min-root union-find => canonical label = smallest id of a cluster):
+//   [0,N)                 P(0,v): the part of worldline v that contains p=0
+//   [N, N+C)              N+k   : the segment opened by the k-th cut in p order (C = number of transverse ops);
+//                                 dense ids come from the per-chunk transverse counts kept by the diagonal pass
+//   [N+C, N+C+(W-1)N)     P(w,v): "whatever segment v is in when wave w's range begins" — artificial ids, larger
+//                                 than every real id so they are never roots; joined to the real segments after
+//                                 the scan (cluster_pass).
 template <int W, int K, bool CL, bool APPLY, bool G>
 __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<G> &uf,
-                                             uint32_t &gr, uint32_t &ncuts_out) {
+                                             uint32_t C) {
     constexpr int NT = W * 64;
+    constexpr uint32_t TS = 64 * K; // slots per wave-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t N = B.N;
     uint32_t *ops = B.ops + (size_t)r * B.cap;
-    const uint32_t o_mycur = L.o_cur + wave * N;
-    for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) LDSW(L.o_cur, i) = 0u;
+    const uint32_t h_mycur = (uint32_t)wave * N; // 16-bit element offset of this wave's table inside o_cur
+    for (uint32_t i = tid; i < ((uint32_t)W * N + 1) / 2; i += NT) LDSW(L.o_cur, i) = 0u;
     __syncthreads();
-    const uint32_t ntiles = (M + NT * K - 1) / (NT * K);
+    // this wave's chunk range and the dense id of its first cut
+    const uint32_t used = (M + B.CH - 1) / B.CH;
+    const uint32_t q = (used + W - 1) / W;
+    const uint32_t c0 = min((uint32_t)wave * q, used), c1 = min(c0 + q, used);
     uint32_t cutbase = 0;
-    // deferred writes of the previous tile's cuts into the copies of earlier waves
-    uint32_t pend_v[K], pend_id[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) { pend_v[j] = 0; pend_id[j] = 0; }
+    for (uint32_t c = lane; c < c0; c += 64) cutbase += LDSW(L.o_chtr, c);
+    for (int off = 32; off > 0; off >>= 1) cutbase += __shfl_xor(cutbase, off);
+    const uint32_t pbeg = c0 * B.CH, pend = min(c1 * B.CH, M);
+    const uint32_t my_placeholder_base = wave == 0 ? 0u : N + C + (uint32_t)(wave - 1) * N;
+    const uint32_t idbase = N + cutbase - 1u; // id of the cut with local rank+1 == x is idbase + x
+    if (lane == 0) LDSW(L.o_chg, wave) = idbase; // read back by cluster_pass when it joins the ranges
+    uint32_t nlocal = 0;                      // cuts seen so far in this wave's range
     uint32_t wnext[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const uint32_t p = slot_of<W, K>(0, wave, j, lane);
-        wnext[j] = p < M ? ops[p] : 0u;
-    }
-    for (uint32_t tile = 0; tile < ntiles; ++tile) {
+    for (int j = 0; j < K; ++j) { const uint32_t p = pbeg + j * 64 + lane; wnext[j] = p < pend ? ops[p] : 0u; }
+    for (uint32_t p0 = pbeg; p0 < pend; p0 += TS) {
         uint32_t word[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) word[j] = wnext[j];
-        if (tile + 1 < ntiles) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const uint32_t pn = slot_of<W, K>(tile + 1, wave, j, lane);
-                wnext[j] = pn < M ? ops[pn] : 0u;
-            }
-        }
-        uint32_t va[K], vc[K], kind[K];
-        uint64_t cutmask[K];
-        int wcuts = 0;
+        for (int j = 0; j < K; ++j) { const uint32_t pn = p0 + TS + j * 64 + lane; wnext[j] = pn < pend ? ops[pn] : 0u; }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            va[j] = 0; vc[j] = SSE_NO_VAR; kind[j] = SSE_BOND_TWO_SITE;
-            if (word[j]) {
-                const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(word[j]));
-                va[j] = d.a; vc[j] = d.c; kind[j] = bd_kind(d);
-            }
-            cutmask[j] = __ballot(word[j] != 0u && kind[j] == SSE_BOND_TRANSVERSE);
-            wcuts += popc64(cutmask[j]);
-        }
-        const int buf = gr & 1;
-        if (lane == 0) LDSI(L.o_tot, buf * W + wave) = wcuts;
-        __syncthreads(); // (A)
-        gr++;
-        uint32_t wbase = 0, total = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2); if (w2 < wave) wbase += t; total += t; }
-        // previous tile's cuts become visible to earlier waves (everyone finished reading that tile)
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (pend_id[j]) for (int w2 = 0; w2 < wave; ++w2) atomicMax(&LDSW(L.o_cur, w2 * N + pend_v[j]), pend_id[j]);
-        uint32_t id_own[K];
-        uint32_t first_id[K];
-        {
-            uint32_t run = N + cutbase + wbase;
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                first_id[j] = run;
-                id_own[j] = run + popc64(cutmask[j] & lanemask_lt(lane));
-                run += popc64(cutmask[j]);
-                const bool iscut = (cutmask[j] >> lane) & 1ull;
+            // straight-line, predicated code: every LDS read uses a safe index and is issued unconditionally
+            const uint32_t wd = word[j];
+            const bool nonempty = wd != 0u;
+            const Bd d = decode_bond<CL, W>(B, L, nonempty ? sse_op_bond(wd) : 0u);
+            const uint32_t va = d.a, kind = bd_kind(d);
+            const bool two = nonempty & (d.c != SSE_NO_VAR);
+            const uint32_t vc = two ? d.c : va;
+            const bool iscut = nonempty & (kind == SSE_BOND_TRANSVERSE);
+            const uint64_t cutmask = __ballot(iscut);
+            const uint32_t first = idbase + nlocal + 1u;
+            const uint32_t id_own = first + popc64(cutmask & lanemask_lt(lane));
+            // Ordered resolution inside the sub-round: a leg on variable x belongs to the segment of the latest
+            // cut on x at an EARLIER slot.  Fast path (no two cuts of this sub-round share a variable): the cut
+            // lanes publish rank and lane through LDS and every lane compares lanes; otherwise a serial loop
+            // over the cut lanes (ballot + v_readlane) resolves it.
+            const uint32_t xa = LDSHV(L.o_cur, h_mycur + va), xc = LDSHV(L.o_cur, h_mycur + vc);
+            uint32_t seg_a = xa ? idbase + xa : my_placeholder_base + va;
+            uint32_t seg_c = xc ? idbase + xc : my_placeholder_base + vc;
+            if (cutmask) {
+                const uint32_t myrank1 = id_own - idbase; // rank+1 of this lane's cut inside the wave's range
                 if (iscut) {
-                    if (!APPLY) uf.set(id_own[j], id_own[j]);
-                    for (int w2 = wave + 1; w2 < W; ++w2) atomicMax(&LDSW(L.o_cur, w2 * N + va[j]), id_own[j]);
+                    LDSHV(L.o_cur, h_mycur + va) = (uint16_t)myrank1;
+                    LDSWV(L.o_cutlane, wave * 64 + (myrank1 - nlocal - 1u)) = (uint32_t)lane;
                 }
-                pend_v[j] = va[j];
-                pend_id[j] = iscut ? id_own[j] : 0u;
-            }
-        }
-        __syncthreads(); // (B)
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const bool nonempty = word[j] != 0u;
-            const bool iscut = (cutmask[j] >> lane) & 1ull;
-            uint32_t seg_a = 0, seg_c = 0;
-            if (nonempty) {
-                seg_a = LDSW(o_mycur, va[j]);
-                if (vc[j] != SSE_NO_VAR) seg_c = LDSW(o_mycur, vc[j]);
-            }
-            {
-                uint64_t m = cutmask[j];
-                uint32_t idL = first_id[j];
-                while (m) {
-                    const int Ls = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const uint32_t vL = __builtin_amdgcn_readlane(va[j], Ls);
-                    if (lane > Ls) { if (va[j] == vL) seg_a = idL; if (vc[j] == vL) seg_c = idL; }
-                    idL++;
-                }
-            }
-            // this sub-round's cuts become visible to the wave's later sub-rounds (ids grow with p)
-            if (iscut) atomicMax(&LDSW(o_mycur, va[j]), id_own[j]);
-            if (nonempty) {
-                if (seg_a == 0u) seg_a = va[j];
-                if (vc[j] != SSE_NO_VAR && seg_c == 0u) seg_c = vc[j];
-                if (!APPLY) {
-                    atomicOr(&LDSW(L.o_touch, va[j] >> 5), 1u << (va[j] & 31));
-                    if (kind[j] == SSE_BOND_TWO_SITE) {
-                        atomicOr(&LDSW(L.o_touch, vc[j] >> 5), 1u << (vc[j] & 31));
-                        uf_union(uf, seg_a, seg_c);
-                    } else if (kind[j] == SSE_BOND_LONGITUDINAL) {
-                        uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
-                    }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t ya = LDSHV(L.o_cur, h_mycur + va), yc = LDSHV(L.o_cur, h_mycur + vc);
+                const uint64_t dup = __ballot(iscut & (ya != myrank1));
+                if (!dup) {
+                    const uint32_t la = LDSWV(L.o_cutlane, wave * 64 + (ya != xa ? ya - nlocal - 1u : 0u));
+                    const uint32_t lc = LDSWV(L.o_cutlane, wave * 64 + (yc != xc ? yc - nlocal - 1u : 0u));
+                    seg_a = ((ya != xa) & (la < (uint32_t)lane)) ? idbase + ya : seg_a;
+                    seg_c = ((yc != xc) & (lc < (uint32_t)lane)) ? idbase + yc : seg_c;
                 } else {
-                    const uint32_t wd = word[j];
-                    uint32_t in = sse_op_in(wd), out = sse_op_out(wd);
-                    const uint32_t fa = uf.get(seg_a);
-                    if (iscut) {
-                        in ^= fa;
-                        out ^= uf.get(id_own[j]);
-                    } else if (kind[j] == SSE_BOND_TWO_SITE) {
-                        const uint32_t f2 = fa | (uf.get(seg_c) << 1);
-                        in ^= f2; out ^= f2;
-                    } else {
-                        in ^= fa; out ^= fa;
+                    bool lastcut = iscut; // no later cut lane of this sub-round is on the same variable
+                    uint64_t m = cutmask;
+                    uint32_t idL = first;
+                    while (m) {
+                        const int Ls = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const uint32_t vL = __builtin_amdgcn_readlane(va, Ls);
+                        const bool later = lane > Ls, same_a = va == vL;
+                        seg_a = (later & same_a) ? idL : seg_a;
+                        seg_c = (later & (vc == vL)) ? idL : seg_c;
+                        lastcut = lastcut & !((lane < Ls) & same_a);
+                        idL++;
                     }
-                    const uint32_t neww = (wd & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
-                    if (neww != wd) ops[slot_of<W, K>(tile, wave, j, lane)] = neww;
+                    if (iscut & lastcut) LDSHV(L.o_cur, h_mycur + va) = (uint16_t)myrank1; // the last cut wins
                 }
             }
+            nlocal += popc64(cutmask);
+            if (!APPLY) {
+                if (iscut) uf.set(id_own, id_own);
+                if (nonempty) {
+                    atomicOr(&LDSW(L.o_touch, va >> 5), 1u << (va & 31));
+                    atomicOr(&LDSW(L.o_touch, vc >> 5), 1u << (vc & 31));
+                }
+                if (two) uf_union(uf, seg_a, seg_c);
+                if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
+            } else {
+                const uint32_t fa = uf.get(seg_a), fc = uf.get(seg_c), fo = uf.get(iscut ? id_own : seg_a);
+                const uint32_t f2 = two ? (fc << 1) : 0u;
+                const uint32_t in = sse_op_in(wd) ^ (fa | f2), out = sse_op_out(wd) ^ (fo | f2);
+                const uint32_t neww = (wd & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
+                if (nonempty & (neww != wd)) ops[p0 + j * 64 + lane] = neww;
+            }
         }
-        cutbase += total;
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (pend_id[j]) for (int w2 = 0; w2 < wave; ++w2) atomicMax(&LDSW(L.o_cur, w2 * N + pend_v[j]), pend_id[j]);
-    __syncthreads();
-    ncuts_out = cutbase;
 }
 
 // Cluster update.  Reference: ClusterUpdater::flip_each_cluster_rng (qmc_traits/cluster.rs:36-172) with the
@@ -604,7 +601,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     const uint32_t N = B.N, nwords = B.nwords;
     UFA<UF_GLOBAL> uf;
     {
-        const size_t ids = (size_t)N + B.cap;
+        const size_t ids = (size_t)W * N + B.cap;
         uf.gparent = B.uf_scratch + (size_t)r * (ids + 2 * ((ids + 31) / 32));
         uf.gfrozen = uf.gparent + ids;
         uf.gfroot = uf.gfrozen + (ids + 31) / 32;
@@ -613,23 +610,29 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     for (uint32_t i = tid; i < nwords; i += NT) LDSW(L.o_touch, i) = 0u;
     if (tid == 0) { LDSW(L.o_misc, MISC_NCLUST) = 0u; LDSW(L.o_misc, MISC_ANYFROZEN) = 0u; }
     if (n == 0) { __syncthreads(); return 0u; } // cluster.rs:46-48
-    const uint32_t S = N + (uint32_t)ntrans; // ids: N placeholders + one per cut (transverse op)
+    SSE_STAMP_INIT;
+    const uint32_t C = (uint32_t)ntrans;            // one id per cut (transverse op)
+    const uint32_t S = N + C + (uint32_t)(W - 1) * N; // + artificial range-boundary placeholders
     for (uint32_t i = tid; i < N; i += NT) uf.set(i, i);
+    for (uint32_t i = tid; i < (uint32_t)(W - 1) * N; i += NT) uf.set(N + C + i, N + C + i);
     for (uint32_t i = tid; i < (S + 31) / 32; i += NT) uf.bits_clear(i);
     __syncthreads();
     // ---- build: label legs with segment ids, union through non-boundary ops ----
-    uint32_t ncuts = 0;
-    cluster_scan<W, K, CL, false, UF_GLOBAL>(B, L, r, M, uf, gr, ncuts);
-    // wrap-around: the part of worldline v before its first cut continues the segment of its last cut.
-    // A wave applies its own cuts to its own copy and to every other wave's copy, so after the scan the
-    // last cut on v is the maximum over all copies.
-    for (uint32_t v = tid; v < N; v += NT) {
-        uint32_t last = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) { const uint32_t x = LDSW(L.o_cur, w2 * N + v); last = x > last ? x : last; }
-        if (last) uf_union(uf, v, last);
+    SSE_STAMP(0);
+    cluster_scan<W, K, CL, false, UF_GLOBAL>(B, L, r, M, uf, C);
+    SSE_STAMP(1);
+    // join the ranges: the segment v is in when wave w's range ends continues into P(w+1,v); the last
+    // range wraps around into P(0,v) (cluster.rs:223-242: worldlines are cyclic in imaginary time)
+    for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) {
+        const uint32_t w2 = i / N, v = i - w2 * N;
+        const uint32_t x = LDSH(L.o_cur, i);
+        const uint32_t last = x ? LDSW(L.o_chg, w2) + x : 0u;
+        const uint32_t seg_end = last ? last : (w2 == 0 ? v : N + C + (w2 - 1) * N + v);
+        const uint32_t nxt = (w2 + 1 == (uint32_t)W) ? v : N + C + w2 * N + v;
+        if (seg_end != nxt) uf_union(uf, seg_end, nxt);
     }
     __syncthreads();
+    SSE_STAMP(2);
     // ---- flatten: parent[i] := exact root (no union runs any more), frozen marks move to roots ----
     for (uint32_t i = tid; i < S; i += NT) {
         const uint32_t root = uf_find(uf, i);
@@ -637,20 +640,22 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
         if ((uf.frozen_get(i >> 5) >> (i & 31)) & 1u) { uf.froot_or(root >> 5, 1u << (root & 31)); LDSW(L.o_misc, MISC_ANYFROZEN) = 1u; }
     }
     __syncthreads();
+    SSE_STAMP(3);
     // ---- coins: each thread reads only parent[i] of its own ids, so parent[i] := flip bit in place ----
     uint32_t myclusters = 0;
-    const bool nocuts = (ncuts == 0u);
+    const bool nocuts = (C == 0u);
     const uint32_t anyfrozen = LDSW(L.o_misc, MISC_ANYFROZEN);
     for (uint32_t i = tid; i < S; i += NT) {
         const uint32_t root = uf.get(i);
-        const bool touched = i >= N || ((LDSW(L.o_touch, i >> 5) >> (i & 31)) & 1u);
+        const uint32_t vi = i < N ? i : (i - N - C) % N; // variable of a placeholder id (nocuts: every id is one)
+        const bool touched = (i >= N && !nocuts) || ((LDSW(L.o_touch, vi >> 5) >> (vi & 31)) & 1u);
         uint32_t f;
         if (nocuts) {
             // no cluster boundary anywhere: the whole graph is one cluster (cluster.rs:98-107), label 0
             const uint4 o = rng.draw(SSE_TAG_CLUSTER, 0u);
             f = (touched && !anyfrozen && u01(o.x) < prob) ? 1u : 0u;
         } else {
-            if (root == i && touched) myclusters++;
+            if (root == i && touched && i < N + C) myclusters++;
             const uint4 o = rng.draw(SSE_TAG_CLUSTER, root);
             const uint32_t isfrozen = (uf.froot_get(root >> 5) >> (root & 31)) & 1u;
             f = (!isfrozen && u01(o.x) < prob) ? 1u : 0u;
@@ -663,9 +668,10 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
         if (lane == 0 && c) atomicAdd(&LDSW(L.o_misc, MISC_NCLUST), c);
     }
     __syncthreads();
+    SSE_STAMP(4);
     // ---- apply (cluster.rs:139-167) ----
-    uint32_t ncuts2 = 0;
-    cluster_scan<W, K, CL, true, UF_GLOBAL>(B, L, r, M, uf, gr, ncuts2);
+    cluster_scan<W, K, CL, true, UF_GLOBAL>(B, L, r, M, uf, C);
+    SSE_STAMP(5);
     // p=0 state follows the placeholder segment of each touched variable
     for (uint32_t i = tid; i < nwords; i += NT) {
         uint32_t x = 0;
@@ -735,16 +741,25 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
     if (n == 0) return 0u;
     const uint4 o0 = rng.draw(SSE_TAG_LOOP, 0u);
     const uint32_t nth = __umulhi(o0.x, (uint32_t)n);
-    // ---- start vertex: the nth occupied slot in p order (chunks of U*NT slots, wave-major inside) ----
-    uint32_t cbase = 0;
+    // ---- start vertex: the nth occupied slot in p order.  The per-chunk occupancy kept by the diagonal pass
+    // names the chunk; only that chunk is scanned (sub-tiles of U*NT slots, wave-major inside) ----
+    uint32_t cbase = 0, qbeg = 0, qend = M;
+    {
+        const uint32_t used = (M + B.CH - 1) / B.CH;
+        for (uint32_t c = 0; c < used; ++c) {
+            const uint32_t cn = LDSW(L.o_chn, c);
+            if (nth < cbase + cn) { qbeg = c * B.CH; qend = min(qbeg + B.CH, M); break; }
+            cbase += cn;
+        }
+    }
     if (tid == 0) LDSW(L.o_misc, MISC_LOOP_A) = 0xFFFFFFFFu;
     __syncthreads();
-    for (uint32_t q0 = 0; q0 < M; q0 += U * NT) {
+    for (uint32_t q0 = qbeg; q0 < qend; q0 += U * NT) {
         uint32_t wd[U];
         uint64_t occ[U];
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < U; ++j) { const uint32_t p = q0 + (uint32_t)(wave * 64 * U + j * 64 + lane); wd[j] = p < M ? ops[p] : 0u; }
+        for (int j = 0; j < U; ++j) { const uint32_t p = q0 + (uint32_t)(wave * 64 * U + j * 64 + lane); wd[j] = p < qend ? ops[p] : 0u; }
 #pragma unroll
         for (int j = 0; j < U; ++j) { occ[j] = __ballot(wd[j] != 0u); cnt += popc64(occ[j]); }
         const int buf = gr & 1;
@@ -882,6 +897,7 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
     for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_state, i) = B.state[(size_t)r * B.nwords + i];
     if constexpr (CL)
         for (uint32_t i = tid; i < B.E; i += NT) LDSW(L.o_edges, i) = B.edges_compact[i];
+    for (uint32_t i = tid; i < 2 * SSE_MAX_CHUNKS; i += NT) LDSW(L.o_chn, i) = B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i];
     __syncthreads();
     int n = (int)B.n[r], ntrans = (int)B.ntrans[r];
     uint32_t M = B.cutoff[r], err = B.err[r], gr = 0, last_out = 0;
@@ -910,7 +926,7 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
         }
         if (A.domask & SSE_DO_CLUSTER) {
             const Rng rng = make_rng(B, r, epoch);
-            if (B.N + (uint32_t)ntrans <= B.lds_ufcap) last_out = cluster_pass<W, K, CL, false>(B, L, r, rng, A.prob, M, n, ntrans, gr);
+            if ((uint32_t)W * B.N + (uint32_t)ntrans <= B.lds_ufcap) last_out = cluster_pass<W, K, CL, false>(B, L, r, rng, A.prob, M, n, ntrans, gr);
             else last_out = cluster_pass<W, K, CL, true>(B, L, r, rng, A.prob, M, n, ntrans, gr);
             epoch++;
             a4 += (uint64_t)n;
@@ -936,6 +952,7 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
     }
     __syncthreads();
     for (uint32_t i = tid; i < B.nwords; i += NT) B.state[(size_t)r * B.nwords + i] = LDSW(L.o_state, i);
+    for (uint32_t i = tid; i < 2 * SSE_MAX_CHUNKS; i += NT) B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i] = LDSW(L.o_chn, i);
     if (tid == 0) {
         B.n[r] = (uint32_t)n; B.ntrans[r] = (uint32_t)ntrans; B.cutoff[r] = M; B.err[r] = err; B.epoch[r] = epoch;
         if (A.out_u32) A.out_u32[r] = last_out;

@@ -32,3 +32,10 @@ t(lambda: g.run(1, beta), "timestep diag+cluster+free")
 t(lambda: g.run(1, beta, flags=im.FLAG_LOOP), "timestep +loop")
 t(lambda: g.run(1, beta, flags=im.FLAG_HEATBATH), "timestep heatbath")
 t(lambda: g.run(10, beta), "10 timesteps fused")
+
+tk = g.debug_phase_ticks()
+if tk.any():
+    g.debug_phase_ticks(reset=True)
+    g.single_cluster_step(flip_free=False)
+    tk = g.debug_phase_ticks().astype(float).mean(axis=0) * 10e-3  # us
+    print("cluster phases (us per replica): init %.1f build %.1f join %.1f flatten %.1f coins %.1f apply %.1f" % tuple(tk[:6]))
