@@ -254,7 +254,10 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (W != 1 && W != 4 && W != 8 && W != 16) { b->err = "waves_per_replica must be 1, 4, 8 or 16"; return fail(ISINGMC_EINVAL); }
     if (K != 1 && K != 2 && K != 4) { b->err = "slots_per_lane must be 1, 2 or 4"; return fail(ISINGMC_EINVAL); }
     // compact edge table staged in LDS when it is small enough (a|c<<15|pref<<30 needs N <= 32768)
-    const bool CL = D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
+    // uniform |J| lets the kernels keep the two-site weight in a scalar register
+    D.uniformJ = 1u; D.wJ = tab[0].w;
+    for (uint32_t e = 1; e < D.E; ++e) if (tab[e].w != tab[0].w) { D.uniformJ = 0u; break; }
+    const bool CL = D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
     const uint32_t ledges = CL ? D.E : 0u;
     while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : W >> 1;
     const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges);
@@ -275,9 +278,6 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     D.lds_ufcap = (uint32_t)ufcap;
     b->W = W; b->K = K; b->CL = CL ? 1u : 0u;
     b->lds_bytes = 4 * (fixed + ufcap + 2 * ((ufcap + 31) / 32));
-    // uniform |J| lets the kernels keep the two-site weight in a scalar register
-    D.uniformJ = 1u; D.wJ = tab[0].w;
-    for (uint32_t e = 1; e < D.E; ++e) if (tab[e].w != tab[0].w) { D.uniformJ = 0u; break; }
     D.gamma = cfg->transverse; D.wh = 2.0 * std::fabs(cfg->longitudinal); D.hpos = cfg->longitudinal > 0.0 ? 1u : 0u;
 
     int rc;

@@ -135,10 +135,12 @@ extern __shared__ __align__(16) uint32_t lds_raw[];
 #define LDSW(off, i) lds_raw[(off) + (i)]
 #define LDSI(off, i) (reinterpret_cast<int &>(lds_raw[(off) + (i)]))
 #define LDSH(off, i) (reinterpret_cast<uint16_t *>(lds_raw)[2u * (off) + (i)]) // 16-bit element i of the array at word offset off
-// volatile forms for tables that OTHER lanes of the same wave write between two reads of one lane (the C++
-// memory model would let the compiler reuse the first value); LDS operations of a wave execute in order.
-#define LDSHV(off, i) (reinterpret_cast<volatile uint16_t *>(lds_raw)[2u * (off) + (i)])
-#define LDSWV(off, i) (reinterpret_cast<volatile uint32_t *>(lds_raw)[(off) + (i)])
+// Tables that OTHER lanes of the same wave write between two reads of one lane need a wavefront-scope fence
+// between the writes and the re-reads (the C++ memory model would otherwise let the compiler reuse the first
+// value).  It emits no instruction: LDS operations of one wave execute in order.
+#define SSE_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#define LDSHV(off, i) LDSH(off, i)
+#define LDSWV(off, i) LDSW(off, i)
 
 template <int W>
 struct Lds {           // word offsets into lds_raw
@@ -189,8 +191,7 @@ __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, ui
         d.c = two ? ((e >> 15) & SSE_CE_VAR_MASK) : SSE_NO_VAR;
         d.kp = two ? (SSE_BOND_TWO_SITE | (((e >> 30) & 1u) << 2))
                    : (tr ? SSE_BOND_TRANSVERSE : (SSE_BOND_LONGITUDINAL | (B.hpos << 2)));
-        const double w2 = B.uniformJ ? B.wJ : B.edge_w[two ? b : 0u];
-        d.w = two ? w2 : (tr ? B.gamma : B.wh);
+        d.w = two ? B.wJ : (tr ? B.gamma : B.wh); // CL mode is only selected for uniform |J| (scalar weights)
     } else {
         const uint4 q = *reinterpret_cast<const uint4 *>(B.bonds + b);
         d.a = q.x & SSE_VAR_MASK; d.c = q.y; d.kp = q.x >> SSE_INFO_SHIFT;
@@ -536,6 +537,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             // cut on x at an EARLIER slot.  Fast path (no two cuts of this sub-round share a variable): the cut
             // lanes publish rank and lane through LDS and every lane compares lanes; otherwise a serial loop
             // over the cut lanes (ballot + v_readlane) resolves it.
+            SSE_WAVE_FENCE();
             const uint32_t xa = LDSHV(L.o_cur, h_mycur + va), xc = LDSHV(L.o_cur, h_mycur + vc);
             uint32_t seg_a = xa ? idbase + xa : my_placeholder_base + va;
             uint32_t seg_c = xc ? idbase + xc : my_placeholder_base + vc;
@@ -545,7 +547,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                     LDSHV(L.o_cur, h_mycur + va) = (uint16_t)myrank1;
                     LDSWV(L.o_cutlane, wave * 64 + (myrank1 - nlocal - 1u)) = (uint32_t)lane;
                 }
-                __builtin_amdgcn_wave_barrier();
+                SSE_WAVE_FENCE();
                 const uint32_t ya = LDSHV(L.o_cur, h_mycur + va), yc = LDSHV(L.o_cur, h_mycur + vc);
                 const uint64_t dup = __ballot(iscut & (ya != myrank1));
                 if (!dup) {

@@ -58,7 +58,9 @@ def test_primitives_step_by_step(oracle, name, edges, gamma, h, beta, waves, k, 
     R = 4
     g, m, reps = make_pair(oracle, edges, gamma, h, 16, 8192, 1234, R, waves, k=k, cfg_flags=cfgf)
     info = g.launch_info()
-    assert info["waves_per_replica"] == waves and info["slots_per_lane"] == k and info["lds_edge_table"] == (cfgf == 0)
+    uniform = len({abs(j) for _, j in edges}) == 1
+    assert info["waves_per_replica"] == waves and info["slots_per_lane"] == k
+    assert info["lds_edge_table"] == (cfgf == 0 and uniform)
     for it in range(12):
         g.single_diagonal_step(beta)
         for rep in reps:
