@@ -247,7 +247,9 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
     }
     __syncthreads();
 
+    SSE_STAMP_INIT;
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
+        SSE_STAMP(11);
         uint32_t word[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) word[j] = wnext[j];
@@ -336,6 +338,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             }
         }
 
+        SSE_STAMP(8);
         // ---- fixed point on n ----
         int npref[K], dec[K], dec_prev[K];
 #pragma unroll
@@ -396,6 +399,9 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 anychg |= LDSW(L.o_chg, buf * W + w2);
             }
             gr++;
+#ifdef SSE_PHASE_TIMING
+            if (threadIdx.x == 0) B.dbg[(size_t)r * 16 + 13] += 1; // rounds
+#endif
             if (dec_prev[0] != 2 && !anychg) break;
             int run = n_start + base;
 #pragma unroll
@@ -405,6 +411,10 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 dec_prev[j] = dec[j];
             }
         }
+        SSE_STAMP(9);
+#ifdef SSE_PHASE_TIMING
+        if (threadIdx.x == 0) B.dbg[(size_t)r * 16 + 12] += 1; // tiles
+#endif
         // ---- commit ----
 #pragma unroll
         for (int j = 0; j < K; ++j) {

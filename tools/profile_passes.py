@@ -39,3 +39,7 @@ if tk.any():
     g.single_cluster_step(flip_free=False)
     tk = g.debug_phase_ticks().astype(float).mean(axis=0) * 10e-3  # us
     print("cluster phases (us per replica): init %.1f build %.1f join %.1f flatten %.1f coins %.1f apply %.1f" % tuple(tk[:6]))
+    g.debug_phase_ticks(reset=True)
+    g.single_diagonal_step(beta)
+    raw = g.debug_phase_ticks().astype(float).mean(axis=0)
+    print("diag phases (us per replica): compute %.1f rounds %.1f commit+loop %.1f ; tiles %.0f rounds %.0f" % (raw[8] * 10e-3, raw[9] * 10e-3, raw[11] * 10e-3, raw[12], raw[13]))
