@@ -119,6 +119,23 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
 /* Verify::verify (qmc_ising.rs:829-860; op_container.rs:137-159), ok[R] */
 int isingmc_verify(isingmc_batch *b, uint8_t *ok);
 
+/* ---- parallel tempering (src/sse/parallel_tempering/tempering_container.rs) -------------------------------
+ * Configurations never move: a tempering swap exchanges the TEMPERATURE LABELS of two configurations (the
+ * reference swaps (manager,state) between (graph,beta) slots, qmc_ising.rs:593-602 — the same thing seen
+ * from the other side).  The per-replica beta[] argument of isingmc_timesteps carries the current labels. */
+/* TemperingContainer::tempering_step decisions (:121-149, :241-302) for nchains independent chains of ntemps
+ * temperatures sharing one Hamiltonian; host-side control logic exactly like the reference's container.
+ *   betas[ntemps]; n_of_config[nchains*ntemps] = operator count of every configuration (global ids);
+ *   config_at[ntemps*nchains] in/out: configuration id at slot t*nchains+chain; *nswaps += swaps done.
+ * Philox tag PT: replica field = chain, epoch = step, index 0 = order coin, 1+t = pair (t,t+1). */
+int isingmc_pt_decide(uint64_t seed, uint64_t step, uint32_t nchains, uint32_t ntemps, const double *betas,
+                      const uint32_t *n_of_config, uint32_t *config_at, uint64_t *nswaps);
+/* set_op_cutoff for every replica at once (tempering_container.rs:129-137): cutoffs[R], each only grows */
+int isingmc_set_cutoffs(isingmc_batch *b, const uint32_t *cutoffs);
+/* replica r accumulates into row rows[r] of an accumulator table with nrows rows (default: nrows = R, rows[r] = r);
+ * isingmc_get_accumulators then returns [nrows][8].  Used to keep statistics per temperature slot. */
+int isingmc_set_accumulator_rows(isingmc_batch *b, uint32_t nrows, const uint32_t *rows);
+
 /* stream plumbing: use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
 int isingmc_set_stream(isingmc_batch *b, void *hip_stream);
 int isingmc_synchronize(isingmc_batch *b);

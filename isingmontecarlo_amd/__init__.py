@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-__all__ = ["QmcIsingGraph", "Qmc", "IsingMcError", "load_library", "op_make", "op_fields",
+__all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
            "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES"]
 
 FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
@@ -65,6 +65,9 @@ SYMBOLS = {
     "isingmc_export_ops": (C.c_int, [_vp, _u32, _P(_u32), _u32]),
     "isingmc_import_ops": (C.c_int, [_vp, _u32, _P(_u32), _u32]),
     "isingmc_verify": (C.c_int, [_vp, _P(C.c_uint8)]),
+    "isingmc_pt_decide": (C.c_int, [_u64, _u64, _u32, _u32, _P(_f64), _P(_u32), _P(_u32), _P(_u64)]),
+    "isingmc_set_cutoffs": (C.c_int, [_vp, _P(_u32)]),
+    "isingmc_set_accumulator_rows": (C.c_int, [_vp, _u32, _P(_u32)]),
     "isingmc_set_stream": (C.c_int, [_vp, _vp]),
     "isingmc_set_steps_per_launch": (C.c_int, [_vp, _u64]),
     "isingmc_debug_phase_ticks": (C.c_int, [_vp, _P(_u64), C.c_int]),
@@ -156,6 +159,7 @@ class QmcIsingGraph:
         self._h = h
         self.capacity = int(capacity)
         self._flags = 0
+        self._acc_rows = self.nreplicas
 
     # ---- lifetime ----
     def close(self):
@@ -193,7 +197,7 @@ class QmcIsingGraph:
         self.reset_accumulators()
         b = self._betas(beta)
         self._check(self._lib.isingmc_timesteps(self._h, int(t), _ptr(b, C.c_double), int(sampling_freq), f))
-        acc = self.accumulators()
+        acc = self.accumulators()[:self.nreplicas]
         with np.errstate(divide="ignore", invalid="ignore"):
             avg_n = acc[:, 0] / acc[:, 1]
         return self.get_energy_for_average_n(avg_n, b)
@@ -226,8 +230,18 @@ class QmcIsingGraph:
         self._check(self._lib.isingmc_flip_free_spins(self._h))
 
     # ---- observables / accessors ----
+    def set_accumulator_rows(self, nrows, rows):
+        """Replica r accumulates into row rows[r] of an [nrows][8] table (per-temperature statistics in PT)."""
+        rw = np.ascontiguousarray(np.asarray(rows, dtype=np.uint32))
+        self._check(self._lib.isingmc_set_accumulator_rows(self._h, int(nrows), _ptr(rw, C.c_uint32)))
+        self._acc_rows = int(nrows)
+
+    def set_cutoffs(self, cutoffs):
+        c = np.ascontiguousarray(np.asarray(cutoffs, dtype=np.uint32))
+        self._check(self._lib.isingmc_set_cutoffs(self._h, _ptr(c, C.c_uint32)))
+
     def accumulators(self):
-        out = np.zeros((self.nreplicas, 8), dtype=np.uint64)
+        out = np.zeros((self._acc_rows, 8), dtype=np.uint64)
         self._check(self._lib.isingmc_get_accumulators(self._h, _ptr(out, C.c_uint64)))
         return out
 
@@ -351,3 +365,6 @@ class Qmc(QmcIsingGraph):
 
     def flip_free_bits(self):
         self.flip_free_spins()
+
+
+from .tempering import TemperingContainer, pt_decide  # noqa: E402

@@ -18,6 +18,8 @@ struct isingmc_batch {
     DevBatch dev{};
     uint32_t W = 8, K = 4, CL = 0;
     uint64_t steps_per_launch = 0;
+    uint32_t acc_rows = 0;
+    uint32_t *d_acc_row = nullptr;
     size_t lds_bytes = 0;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -290,6 +292,14 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if ((rc = dalloc(b, &D.aux, D.R))) return fail(rc);
     if ((rc = dalloc(b, &D.epoch, D.R))) return fail(rc);
     if ((rc = dalloc(b, &D.acc, (size_t)D.R * 8))) return fail(rc);
+    b->acc_rows = D.R;
+    if ((rc = dalloc(b, &b->d_acc_row, D.R))) return fail(rc);
+    {
+        std::vector<uint32_t> ident(D.R);
+        for (uint32_t i = 0; i < D.R; ++i) ident[i] = i;
+        if (hipMemcpy(b->d_acc_row, ident.data(), sizeof(uint32_t) * D.R, hipMemcpyHostToDevice) != hipSuccess) { b->err = "acc_row upload failed"; return fail(ISINGMC_ENODEVICE); }
+        D.acc_row = b->d_acc_row;
+    }
     if ((rc = dalloc(b, &D.chunks, (size_t)D.R * 2 * SSE_MAX_CHUNKS))) return fail(rc);
     if ((rc = dalloc(b, &D.dbg, (size_t)D.R * 16))) return fail(rc);
     BondRec *dbonds = nullptr; double *dcum = nullptr;
@@ -379,13 +389,81 @@ int isingmc_timesteps(isingmc_batch *b, uint64_t t, const double *beta, uint32_t
 int isingmc_get_accumulators(isingmc_batch *b, uint64_t *out) {
     if (!b || !out) return ISINGMC_EINVAL;
     HIP_TRY(b, hipSetDevice(b->device));
-    HIP_TRY(b, hipMemcpy(out, b->dev.acc, sizeof(uint64_t) * 8 * b->dev.R, hipMemcpyDeviceToHost));
+    HIP_TRY(b, hipMemcpy(out, b->dev.acc, sizeof(uint64_t) * 8 * b->acc_rows, hipMemcpyDeviceToHost));
     return ISINGMC_OK;
 }
 int isingmc_reset_accumulators(isingmc_batch *b) {
     if (!b) return ISINGMC_EINVAL;
     HIP_TRY(b, hipSetDevice(b->device));
-    HIP_TRY(b, hipMemset(b->dev.acc, 0, sizeof(uint64_t) * 8 * b->dev.R));
+    HIP_TRY(b, hipMemset(b->dev.acc, 0, sizeof(uint64_t) * 8 * b->acc_rows));
+    return ISINGMC_OK;
+}
+int isingmc_set_accumulator_rows(isingmc_batch *b, uint32_t nrows, const uint32_t *rows) {
+    if (!b || !rows || nrows == 0) return ISINGMC_EINVAL;
+    for (uint32_t r = 0; r < b->dev.R; ++r) if (rows[r] >= nrows) { b->err = "accumulator row out of range"; return ISINGMC_EINVAL; }
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    if (nrows != b->acc_rows) {
+        uint64_t *na = nullptr;
+        int rc = dalloc(b, &na, (size_t)nrows * 8);
+        if (rc) return rc;
+        b->dev.acc = na; // the previous table stays in the allocation list until destroy
+        b->acc_rows = nrows;
+    }
+    HIP_TRY(b, hipMemcpy(b->d_acc_row, rows, sizeof(uint32_t) * b->dev.R, hipMemcpyHostToDevice));
+    return ISINGMC_OK;
+}
+int isingmc_set_cutoffs(isingmc_batch *b, const uint32_t *cutoffs) {
+    if (!b || !cutoffs) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    std::vector<uint32_t> cur(b->dev.R);
+    HIP_TRY(b, hipMemcpy(cur.data(), b->dev.cutoff, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < b->dev.R; ++r) {
+        if (cutoffs[r] > b->dev.cap) { b->err = "cutoff exceeds capacity"; return ISINGMC_ECAPACITY; }
+        if (cutoffs[r] > cur[r]) cur[r] = cutoffs[r]; // fast_ops.rs:1258-1262: only grows
+    }
+    HIP_TRY(b, hipMemcpy(b->dev.cutoff, cur.data(), sizeof(uint32_t) * b->dev.R, hipMemcpyHostToDevice));
+    return ISINGMC_OK;
+}
+
+// Host-side Philox4x32-10 for the tempering decisions (control logic, not the sweep path).
+static void host_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+int isingmc_pt_decide(uint64_t seed, uint64_t step, uint32_t nchains, uint32_t ntemps, const double *betas,
+                      const uint32_t *n_of_config, uint32_t *config_at, uint64_t *nswaps) {
+    if (!betas || !n_of_config || !config_at || nchains == 0 || ntemps == 0) return ISINGMC_EINVAL;
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint64_t swaps = 0;
+    for (uint32_t chain = 0; chain < nchains && ntemps > 1; ++chain) {
+        uint32_t ctr[4] = {0u, (uint32_t)step, chain, (SSE_TAG_PT << 24) | (uint32_t)((step >> 32) & 0xFFFFFFu)};
+        uint32_t o[4];
+        host_philox(ctr, key, o);
+        const bool a_first = (o[0] >> 31) != 0u; // gen_bool(0.5) (tempering_container.rs:140)
+        for (int phase = 0; phase < 2; ++phase) {
+            const bool set_a = (phase == 0) ? a_first : !a_first;
+            for (uint32_t t = set_a ? 0u : 1u; t + 1 < ntemps; t += 2) { // make_first/second_subgraphs (:83-99)
+                ctr[0] = 1u + t;
+                host_philox(ctr, key, o);
+                const double u = (double)o[0] * (1.0 / 4294967296.0);
+                uint32_t &ca = config_at[(size_t)t * nchains + chain], &cb = config_at[(size_t)(t + 1) * nchains + chain];
+                const double dn = (double)((int64_t)n_of_config[cb] - (int64_t)n_of_config[ca]);
+                if (std::pow(betas[t] / betas[t + 1], dn) > u) { // swap_on_chunks (:296-298), equal Hamiltonians
+                    const uint32_t tmp = ca; ca = cb; cb = tmp;
+                    swaps++;
+                }
+            }
+        }
+    }
+    if (nswaps) *nswaps += swaps;
     return ISINGMC_OK;
 }
 double isingmc_get_offset(const isingmc_batch *b) { return b ? b->offset : 0.0; }

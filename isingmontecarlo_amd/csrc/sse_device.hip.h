@@ -40,7 +40,8 @@ struct DevBatch {
     uint32_t *state;      // [R][nwords] bit v of word v>>5
     uint32_t *n, *ntrans, *cutoff, *err, *aux;  // [R]
     uint64_t *epoch;      // [R]
-    uint64_t *acc;        // [R][8]
+    uint64_t *acc;        // [acc_rows][8]
+    const uint32_t *acc_row; // [R] accumulator row of each replica
     const BondRec *bonds; // [Nb]
     const uint32_t *edges_compact; // [E] or null
     const double *edge_w; // [E] 2|J|
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
     if (tid == 0) {
         B.n[r] = (uint32_t)n; B.ntrans[r] = (uint32_t)ntrans; B.cutoff[r] = M; B.err[r] = err; B.epoch[r] = epoch;
         if (A.out_u32) A.out_u32[r] = last_out;
-        uint64_t *acc = B.acc + (size_t)r * 8;
+        uint64_t *acc = B.acc + (size_t)B.acc_row[r] * 8;
         acc[0] += a0; acc[1] += a1; acc[2] += a2; acc[3] += a3; acc[4] += a4; acc[5] += a5; acc[6] += a6;
     }
 }

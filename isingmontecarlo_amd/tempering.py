@@ -1,0 +1,173 @@
+"""Parallel tempering over the batch engine.
+
+Host-side mirror of qmc::sse::parallel_tempering::TemperingContainer
+(src/sse/parallel_tempering/tempering_container.rs) for `nchains` independent chains ("walkers") of `ntemps`
+temperatures that share one Hamiltonian.  Configurations never move: a swap exchanges temperature labels.
+
+Global layout (independent of how the job is sharded over GPUs):
+    configuration id  c = t0 * nchains + chain   (t0 = temperature the configuration started at)
+    slot id           s = t  * nchains + chain   (t  = temperature index)
+Rank g of G owns the configurations with t0 in its contiguous temperature block, i.e. a contiguous id range,
+so `replica_offset` makes the device Philox streams identical to the single-GPU run.  One tempering step
+all-gathers (n, cutoff) of every configuration (RCCL over xGMI when the backend is nccl: 8 B per replica),
+after which every rank evaluates the same swap decisions (counter-based Philox keyed by step and pair) and
+relabels its own configurations.  No op-string ever crosses a link.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+def _lib():
+    from . import load_library
+    return load_library()
+
+
+def pt_decide(seed, step, nchains, ntemps, betas, n_of_config, config_at):
+    """TemperingContainer::tempering_step decisions (tempering_container.rs:121-149,241-302) through the C ABI.
+    `config_at` (uint32[ntemps*nchains]) is permuted in place; returns the number of swaps."""
+    b = np.ascontiguousarray(np.asarray(betas, dtype=np.float64))
+    n = np.ascontiguousarray(np.asarray(n_of_config, dtype=np.uint32))
+    assert config_at.dtype == np.uint32 and config_at.flags.c_contiguous
+    sw = C.c_uint64(0)
+    rc = _lib().isingmc_pt_decide(int(seed), int(step), int(nchains), int(ntemps), b.ctypes.data_as(C.POINTER(C.c_double)),
+                                  n.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  config_at.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(sw))
+    if rc != 0:
+        raise RuntimeError("isingmc_pt_decide failed")
+    return int(sw.value)
+
+
+class _Collective:
+    """all-gather of small integer arrays: torch.distributed when initialised (nccl = RCCL on ROCm), else local."""
+
+    def __init__(self, device=None):
+        self.dist = None
+        self.device = device
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                self.dist = dist
+        except Exception:  # torch not importable: single process
+            self.dist = None
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+
+    def all_gather_u32(self, local):
+        if not self.dist:
+            return local.copy()
+        import torch
+        dev = self.device if self.device is not None else ("cuda" if self.dist.get_backend() == "nccl" else "cpu")
+        t = torch.from_numpy(local.astype(np.int64)).to(dev)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return torch.cat(outs).cpu().numpy().astype(np.uint32)
+
+    def all_reduce_sum_u64(self, local):
+        if not self.dist:
+            return local.copy()
+        import torch
+        dev = self.device if self.device is not None else ("cuda" if self.dist.get_backend() == "nccl" else "cpu")
+        t = torch.from_numpy(local.astype(np.int64)).to(dev)
+        self.dist.all_reduce(t)
+        return t.cpu().numpy().astype(np.uint64)
+
+
+class TemperingContainer:
+    """qmc::sse::parallel_tempering::TemperingContainer, batch-first.
+
+    `backend` must offer: nreplicas, get_n(), get_cutoff(), set_cutoffs(arr), run(t, betas, sampling_freq, flags),
+    set_accumulator_rows(nrows, rows), accumulators(), reset_accumulators(), get_offset(), state_ref(), verify().
+    `QmcIsingGraph` is one; the CPU tests plug in an oracle-backed one.
+    """
+
+    def __init__(self, backend, betas, nchains, seed, flags=0, collective=None):
+        self.b = backend
+        self.betas = np.ascontiguousarray(np.asarray(betas, dtype=np.float64))
+        self.ntemps, self.nchains = len(self.betas), int(nchains)
+        self.seed, self.flags = int(seed), int(flags)
+        self.coll = collective if collective is not None else _Collective()
+        nconf = self.ntemps * self.nchains
+        assert self.ntemps % self.coll.world == 0, "temperatures must divide evenly over the ranks"
+        tper = self.ntemps // self.coll.world
+        self.c0 = self.coll.rank * tper * self.nchains  # first global configuration id owned by this rank
+        assert backend.nreplicas == tper * self.nchains, "backend must hold ntemps/world * nchains replicas"
+        self.config_at = np.arange(nconf, dtype=np.uint32)  # slot -> configuration
+        self.step = 0
+        self.total_swaps = 0
+        self._apply_labels()
+
+    # ---- labels ----
+    def _slot_of_config(self):
+        inv = np.empty_like(self.config_at)
+        inv[self.config_at] = np.arange(len(self.config_at), dtype=np.uint32)
+        return inv
+
+    def _apply_labels(self):
+        slot = self._slot_of_config()[self.c0:self.c0 + self.b.nreplicas]
+        self.local_betas = self.betas[slot // self.nchains]
+        self.b.set_accumulator_rows(self.ntemps * self.nchains, slot)
+
+    # ---- reference API ----
+    def num_graphs(self):
+        return self.ntemps * self.nchains
+
+    def get_total_swaps(self):
+        return self.total_swaps
+
+    def timesteps(self, t, sampling_freq=1):
+        """TemperingContainer::timesteps (:77-81) / parallel_timesteps (:366-371)."""
+        self.b.run(int(t), self.local_betas, sampling_freq, self.flags)
+
+    def tempering_step(self):
+        """TemperingContainer::tempering_step (:121-149): equalise cutoffs per chain, then the a/b pair sets."""
+        if self.ntemps <= 1:
+            return 0
+        n = self.coll.all_gather_u32(np.asarray(self.b.get_n(), dtype=np.uint32))
+        cut = self.coll.all_gather_u32(np.asarray(self.b.get_cutoff(), dtype=np.uint32))
+        chain = np.arange(len(n)) % self.nchains
+        maxcut = np.zeros(self.nchains, dtype=np.uint32)
+        np.maximum.at(maxcut, chain, cut)
+        self.b.set_cutoffs(np.ascontiguousarray(maxcut[chain[self.c0:self.c0 + self.b.nreplicas]]))
+        swaps = pt_decide(self.seed, self.step, self.nchains, self.ntemps, self.betas, n, self.config_at)
+        self.step += 1
+        self.total_swaps += swaps
+        self._apply_labels()
+        return swaps
+
+    def timesteps_sample(self, timesteps, replica_swap_freq, sampling_freq):
+        """parallel_timesteps_sample (:411-453): returns (states per slot, energy sums per slot).
+
+        Like the reference (:187-189, :430-434) the second value is the SUM over blocks of E_block * t_block,
+        not a mean.  States are sampled every `sampling_freq` steps and reported per temperature slot."""
+        nslots = self.num_graphs()
+        states = [[] for _ in range(nslots)]
+        energy_acc = np.zeros(nslots)
+        remaining, to_swap, to_sample = int(timesteps), int(replica_swap_freq), int(sampling_freq)
+        while remaining > 0:
+            t = min(to_sample, to_swap, remaining)
+            self.b.reset_accumulators()
+            self.timesteps(t)
+            acc = self.coll.all_reduce_sum_u64(self.b.accumulators()).astype(np.float64)
+            beta_of_slot = np.repeat(self.betas, self.nchains)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                te = -(acc[:, 0] / acc[:, 1]) / beta_of_slot + self.b.get_offset()
+            energy_acc += np.where(acc[:, 1] > 0, te, 0.0) * t
+            to_sample -= t; to_swap -= t; remaining -= t
+            if to_swap == 0:
+                self.tempering_step()
+                to_swap = int(replica_swap_freq)
+            if to_sample == 0:
+                st = self.b.state_ref()
+                slot = self._slot_of_config()[self.c0:self.c0 + self.b.nreplicas]
+                for i, s in enumerate(slot):
+                    states[int(s)].append(st[i].copy())
+                to_sample = int(sampling_freq)
+        return states, energy_acc
+
+    def slot_accumulators(self):
+        """Global [ntemps*nchains][8] accumulator table (summed over ranks)."""
+        return self.coll.all_reduce_sum_u64(self.b.accumulators())
+
+    def verify(self):
+        return bool(np.all(self.b.verify()))

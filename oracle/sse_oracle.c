@@ -601,3 +601,44 @@ uint32_t ora_get_bond_count(const ora_replica *r, uint32_t bond) {
 }
 void ora_get_accumulators(const ora_replica *r, uint64_t acc[8]) { memcpy(acc, r->acc, sizeof(r->acc)); }
 void ora_reset_accumulators(ora_replica *r) { memset(r->acc, 0, sizeof(r->acc)); }
+
+/* ------------------------------------------------------------------ parallel tempering --- */
+/* TemperingContainer::tempering_step (src/sse/parallel_tempering/tempering_container.rs:121-149) with
+ * perform_swaps (:241-272) and swap_on_chunks (:274-302), for ONE chain of ntemps graphs that share a
+ * Hamiltonian (rel_h_weight = 1, :285-287).  by_slot[t] is the replica currently at temperature t;
+ * swapping graphs (qmc_ising.rs:593-602 swaps manager and state) = swapping the pointers.
+ *   1. every graph's cutoff is raised to the chain maximum (:129-137);
+ *   2. one coin decides whether pair set a = (0,1),(2,3).. or b = (1,2),(3,4).. goes first (:140-146);
+ *   3. each pair draws one uniform u and swaps iff (beta_a/beta_b)^(n_b - n_a) > u (:255, :296-298).
+ * Philox: tag PT, replica field = chain, epoch = step; index 0 = the order coin, index 1+t = the pair whose
+ * lower slot is t.  Returns the number of swaps. */
+uint64_t ora_pt_step(ora_replica **by_slot, const double *betas, uint32_t ntemps, uint64_t seed, uint32_t chain,
+                     uint64_t step) {
+    if (ntemps <= 1) return 0;
+    uint32_t maxcut = 0;
+    for (uint32_t t = 0; t < ntemps; ++t) if (by_slot[t]->cutoff > maxcut) maxcut = by_slot[t]->cutoff;
+    for (uint32_t t = 0; t < ntemps; ++t) ora_set_cutoff(by_slot[t], maxcut);
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t ctr[4] = {0, (uint32_t)step, chain, (SSE_TAG_PT << 24) | (uint32_t)((step >> 32) & 0xFFFFFFu)};
+    uint32_t o[4];
+    ora_philox4x32_10(ctr, key, o);
+    const int a_first = (o[0] >> 31) != 0; /* gen_bool(0.5) */
+    uint64_t swaps = 0;
+    for (int phase = 0; phase < 2; ++phase) {
+        const int set_a = (phase == 0) ? a_first : !a_first;
+        /* make_first_subgraphs / make_second_subgraphs (:83-99) */
+        for (uint32_t t = set_a ? 0u : 1u; t + 1 < ntemps; t += 2) {
+            ctr[0] = 1u + t;
+            ora_philox4x32_10(ctr, key, o);
+            const double u = u01(o[0]);
+            ora_replica *ga = by_slot[t], *gb = by_slot[t + 1];
+            const double p_swap = pow(betas[t] / betas[t + 1], (double)((int64_t)gb->n - (int64_t)ga->n));
+            if (p_swap > u) {
+                by_slot[t] = gb;
+                by_slot[t + 1] = ga;
+                swaps++;
+            }
+        }
+    }
+    return swaps;
+}

@@ -53,6 +53,10 @@ int ora_timestep(ora_replica *r, double beta, uint32_t flags);
 int ora_timesteps(ora_replica *r, uint64_t t, double beta, uint32_t sampling_freq, uint32_t flags);
 int ora_verify(const ora_replica *r);
 
+/* one parallel-tempering step of one chain; by_slot[t] = replica at temperature t (pointers are swapped) */
+uint64_t ora_pt_step(ora_replica **by_slot, const double *betas, uint32_t ntemps, uint64_t seed, uint32_t chain,
+                     uint64_t step);
+
 uint32_t ora_get_n(const ora_replica *r);
 uint32_t ora_get_cutoff(const ora_replica *r);
 int ora_set_cutoff(ora_replica *r, uint32_t cutoff);

@@ -51,6 +51,7 @@ def load():
         "ora_batch_timesteps": (C.c_int, [p(vp), u32, u64, p(f64), u32, u32, C.c_int]),
         "ora_max_threads": (C.c_int, []),
         "ora_philox4x32_10": (None, [p(u32), p(u32), p(u32)]),
+        "ora_pt_step": (u64, [p(vp), p(f64), u32, u64, u32, u64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -187,3 +188,13 @@ def batch_timesteps(replicas, t, betas, freq=1, flags=0, nthreads=0):
     b = np.ascontiguousarray(np.asarray(betas, dtype=np.float64))
     rc = lib().ora_batch_timesteps(arr, len(replicas), t, _ptr(b, C.c_double), freq, flags, nthreads)
     assert rc == 0
+
+
+def pt_step(by_slot, betas, seed, chain, step):
+    """One tempering step of one chain; `by_slot` (list of Replica, index = temperature) is permuted in place."""
+    arr = (C.c_void_p * len(by_slot))(*[r.ptr for r in by_slot])
+    b = np.ascontiguousarray(np.asarray(betas, dtype=np.float64))
+    swaps = lib().ora_pt_step(arr, _ptr(b, C.c_double), len(by_slot), seed, chain, step)
+    lookup = {r.ptr: r for r in by_slot}
+    by_slot[:] = [lookup[arr[i]] for i in range(len(by_slot))]
+    return int(swaps)

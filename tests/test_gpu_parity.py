@@ -148,3 +148,33 @@ def test_capacity_error_is_loud(oracle):
     with pytest.raises(im.IsingMcError) as ei:
         g.run(50, 8.0)
     assert ei.value.code == -3
+
+
+def test_parallel_tempering_matches_oracle(oracle):
+    """TemperingContainer over the GPU batch (labels swap, configurations stay) against the oracle's
+    graph-swapping restatement of tempering_container.rs:121-149: same swaps, same per-slot configurations."""
+    import isingmontecarlo_amd as im
+    from test_tempering_cpu import reference_pt
+    edges = lat.two_d_periodic(4)
+    e, j = lat.split(edges)
+    m = oracle.Model(16, e, j, 1.0, 0.0)
+    betas = np.array([0.5, 0.8, 1.1, 1.5, 2.0, 2.6])
+    K, seed = 4, 2468
+    by_slot, swaps_ref = reference_pt(m, betas, K, seed, 4096, 16, nsteps=15, sweeps_per_step=2)
+    g = im.QmcIsingGraph(edges, 1.0, 0.0, 16, seed, nreplicas=len(betas) * K, capacity=4096)
+    tc = im.TemperingContainer(g, betas, K, seed)
+    for _ in range(15):
+        tc.timesteps(2)
+        tc.tempering_step()
+    assert tc.get_total_swaps() == swaps_ref and swaps_ref > 0
+    st, n, cut = g.state_ref(), g.get_n(), g.get_cutoff()
+    for k in range(K):
+        for t in range(len(betas)):
+            c = int(tc.config_at[t * K + k])
+            ref = by_slot[k][t]
+            assert n[c] == ref.n and cut[c] == ref.cutoff
+            assert np.array_equal(st[c], ref.state())
+            assert np.array_equal(g.export_ops(c), ref.ops())
+    assert tc.verify()
+    acc = tc.slot_accumulators()
+    assert acc.shape == (len(betas) * K, 8) and (acc[:, 1] == 30).all()
