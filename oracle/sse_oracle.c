@@ -6,8 +6,7 @@
  * not depend on evaluation order and can be compared bit-for-bit with the parallel HIP kernels.
  * Citations are relative to /root/reference.
  */
-#include "sse_oracle.h"
-#include "../include/sse_format.h"
+#include "sse_oracle_internal.h"
 
 #include <float.h>
 #include <math.h>
@@ -32,43 +31,6 @@ void ora_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-
-struct ora_model {
-    uint32_t nvars, nedges, nbonds;
-    uint32_t *bond_a, *bond_b, *binfo;
-    double *bweight;
-    double *cumw; /* heat-bath cumulative max weights (heatbath.rs:16-35) */
-    double wtot;
-    double offset, gamma, h;
-};
-
-struct ora_replica {
-    const ora_model *m;
-    uint32_t cap, cutoff, n, replica;
-    uint32_t *ops;
-    uint8_t *state;
-    uint64_t seed, epoch;
-    uint64_t acc[8];
-    /* scratch */
-    uint32_t *parent, *cur;
-    uint8_t *flip, *frozen, *touched;
-};
-
-static void draw(const ora_replica *r, uint32_t tag, uint32_t index, uint32_t out[4]) {
-    uint32_t ctr[4] = {index, (uint32_t)r->epoch, r->replica,
-                       (tag << 24) | (uint32_t)((r->epoch >> 32) & 0xFFFFFFu)};
-    uint32_t key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)};
-    ora_philox4x32_10(ctr, key, out);
-}
-/* Metropolis diagonal pass: one Philox call serves the slot pair (p, p^64): index = p with bit 6 cleared,
- * words (0,1) for the slot with bit 6 clear, words (2,3) for the other (include/sse_format.h). */
-static void draw_diag(const ora_replica *r, uint32_t p, uint32_t out[2]) {
-    uint32_t o[4];
-    draw(r, SSE_TAG_DIAG, p & ~64u, o);
-    if (p & 64u) { out[0] = o[2]; out[1] = o[3]; } else { out[0] = o[0]; out[1] = o[1]; }
-}
-static inline double u01(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
-static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
 /* --------------------------------------------------------------------------- model --- */
 /* Bond numbering and offsets: src/sse/qmc_ising.rs:92-104 (nvars, offsets), :186-205 and :228-246
@@ -127,7 +89,7 @@ uint32_t ora_model_nbonds(const ora_model *m) { return m->nbonds; }
 double ora_model_offset(const ora_model *m) { return m->offset; }
 
 /* matrix element <out|H_b|in> of the shifted bond operator (qmc_ising.rs:863-888) */
-static double bond_weight(const ora_model *m, uint32_t b, uint32_t in, uint32_t out) {
+double ora_bond_weight(const ora_model *m, uint32_t b, uint32_t in, uint32_t out) {
     uint32_t info = m->binfo[b];
     uint32_t pref = (info & SSE_BOND_PREF_BIT) ? 1u : 0u;
     switch (info & SSE_BOND_KIND_MASK) {
@@ -209,7 +171,7 @@ void ora_diagonal_update(ora_replica *r, double beta) {
             draw_diag(r, p, o);
             uint32_t b = mulhi32(o[0], m->nbonds);
             uint32_t s = substate(r, b);
-            double num = beta_nb * bond_weight(m, b, s, s);
+            double num = beta_nb * ora_bond_weight(m, b, s, s);
             double den = (double)(M - r->n);
             if (u01(o[1]) * den < num) {
                 r->ops[p] = sse_op_make(b, s, s);
@@ -219,7 +181,7 @@ void ora_diagonal_update(ora_replica *r, double beta) {
             uint32_t o[2];
             draw_diag(r, p, o);
             uint32_t b = sse_op_bond(w);
-            double num = beta_nb * bond_weight(m, b, sse_op_in(w), sse_op_in(w));
+            double num = beta_nb * ora_bond_weight(m, b, sse_op_in(w), sse_op_in(w));
             double den = (double)(M - r->n + 1u);
             if (u01(o[1]) * num < den) {
                 r->ops[p] = SSE_OP_EMPTY;
@@ -255,7 +217,7 @@ void ora_heatbath_update(ora_replica *r, double beta) {
                 }
                 uint32_t b = lo < m->nbonds ? lo : m->nbonds - 1;
                 uint32_t s = substate(r, b);
-                if (u01(o[1]) * m->bweight[b] < bond_weight(m, b, s, s)) {
+                if (u01(o[1]) * m->bweight[b] < ora_bond_weight(m, b, s, s)) {
                     r->ops[p] = sse_op_make(b, s, s);
                     r->n += 1;
                 }
@@ -460,7 +422,7 @@ uint32_t ora_loop_update(ora_replica *r) {
         for (uint32_t leg = 0; leg < 2 * k; ++leg) {
             uint32_t i2 = in_e, o2 = out_e;
             if (leg < k) i2 ^= 1u << leg; else o2 ^= 1u << (leg - k);
-            wl[leg] = bond_weight(m, b, i2, o2);
+            wl[leg] = ora_bond_weight(m, b, i2, o2);
             total += wl[leg];
         }
         draw(r, SSE_TAG_LOOP, step, o);
@@ -522,6 +484,7 @@ int ora_timestep(ora_replica *r, double beta, uint32_t flags) {
         if (want > r->cap) return 1;
         r->cutoff = want;
     }
+    if (flags & ORA_FLAG_RVB) ora_rvb_update(r, (r->m->nvars + 1) / 2); /* qmc_ising.rs:705-752 */
     if (flags & ORA_FLAG_LOOP) ora_loop_update(r);
     if (!(flags & ORA_FLAG_NO_CLUSTER)) ora_cluster_update(r, 0.5);
     ora_flip_free_spins(r);
@@ -553,7 +516,7 @@ int ora_verify(const ora_replica *r) {
         uint32_t b = sse_op_bond(w);
         if (b >= m->nbonds) { ok = 0; break; }
         uint32_t in = sse_op_in(w), out = sse_op_out(w);
-        if (!(fabs(bond_weight(m, b, in, out)) > DBL_EPSILON)) ok = 0;
+        if (!(fabs(ora_bond_weight(m, b, in, out)) > DBL_EPSILON)) ok = 0;
         uint32_t a = m->bond_a[b], c = m->bond_b[b];
         if (s[a] != (in & 1u)) ok = 0;
         s[a] = (uint8_t)(out & 1u);

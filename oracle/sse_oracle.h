@@ -49,6 +49,11 @@ void ora_heatbath_update(ora_replica *r, double beta);
 uint32_t ora_cluster_update(ora_replica *r, double prob);
 void ora_flip_free_spins(ora_replica *r);
 uint32_t ora_loop_update(ora_replica *r); /* returns number of vertices visited */
+/* RvbUpdater::rvb_update_with_ising_weight (qmc_traits/rvb.rs:88-290): `updates` attempts; returns #accepted */
+uint32_t ora_rvb_update(ora_replica *r, uint32_t updates);
+uint32_t ora_find_overlapping_starts(uint32_t p_start, uint32_t p_end, uint32_t cutoff, const uint32_t *fp, uint32_t L,
+                                     uint32_t *out);
+uint32_t ora_remove_doubles(uint32_t *v, uint32_t n);
 int ora_timestep(ora_replica *r, double beta, uint32_t flags);
 int ora_timesteps(ora_replica *r, uint64_t t, double beta, uint32_t sampling_freq, uint32_t flags);
 int ora_verify(const ora_replica *r);

@@ -52,6 +52,9 @@ def load():
         "ora_max_threads": (C.c_int, []),
         "ora_philox4x32_10": (None, [p(u32), p(u32), p(u32)]),
         "ora_pt_step": (u64, [p(vp), p(f64), u32, u64, u32, u64]),
+        "ora_rvb_update": (u32, [vp, u32]),
+        "ora_find_overlapping_starts": (u32, [u32, u32, u32, p(u32), u32, p(u32)]),
+        "ora_remove_doubles": (u32, [p(u32), u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -127,6 +130,9 @@ class Replica:
     def loop_update(self):
         return lib().ora_loop_update(self.ptr)
 
+    def rvb_update(self, updates):
+        return lib().ora_rvb_update(self.ptr, updates)
+
     def timestep(self, beta, flags=0):
         return lib().ora_timestep(self.ptr, beta, flags)
 
@@ -198,3 +204,16 @@ def pt_step(by_slot, betas, seed, chain, step):
     lookup = {r.ptr: r for r in by_slot}
     by_slot[:] = [lookup[arr[i]] for i in range(len(by_slot))]
     return int(swaps)
+
+
+def find_overlapping_starts(p_start, p_end, cutoff, flips):
+    fp = np.ascontiguousarray(np.asarray(flips, dtype=np.uint32))
+    out = np.zeros(len(fp), dtype=np.uint32)
+    n = lib().ora_find_overlapping_starts(p_start, p_end, cutoff, _ptr(fp, C.c_uint32), len(fp), _ptr(out, C.c_uint32))
+    return out[:n].tolist()
+
+
+def remove_doubles(v):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.uint32))
+    n = lib().ora_remove_doubles(_ptr(a, C.c_uint32), len(a)) if len(a) else 0
+    return a[:n].tolist()

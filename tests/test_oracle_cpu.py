@@ -38,11 +38,11 @@ with open(os.path.join(HERE, "golden", "ed_tfim.json")) as f:
 ED_CASES = [(c, r) for c in ED for r in c["results"]]
 
 
-@pytest.mark.parametrize("flags", [0, O.FLAG_HEATBATH, O.FLAG_LOOP])
+@pytest.mark.parametrize("flags", [0, O.FLAG_HEATBATH, O.FLAG_LOOP, O.FLAG_RVB])
 @pytest.mark.parametrize("case,res", ED_CASES, ids=[f"{c['name']}-b{r['beta']}" for c, r in ED_CASES])
 def test_oracle_matches_exact_diagonalisation(case, res, flags):
-    if flags and case["nvars"] > 8:
-        pytest.skip("variants are checked on the small systems")
+    if flags and case["nvars"] > 8 and not (flags == O.FLAG_RVB and case["name"] == "lat3x3_villain"):
+        pytest.skip("variants are checked on the small systems (RVB also on the frustrated 3x3 Villain lattice)")
     m = O.Model(case["nvars"], case["edges"], case["J"], case["gamma"], case["h"])
     beta, R = res["beta"], 16
     reps = [O.Replica(m, 4096, case["nvars"], 20240 + flags, r) for r in range(R)]
@@ -79,7 +79,7 @@ CRASH = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, O.FLAG_HEATBATH, O.FLAG_LOOP])
+@pytest.mark.parametrize("flags", [0, O.FLAG_HEATBATH, O.FLAG_LOOP, O.FLAG_RVB, O.FLAG_RVB | O.FLAG_HEATBATH])
 @pytest.mark.parametrize("name,edges,gamma,h,cutoff", CRASH, ids=[c[0] for c in CRASH])
 def test_reference_crash_graphs_stay_consistent(name, edges, gamma, h, cutoff, flags):
     e, j = lat.split(edges)
@@ -161,3 +161,37 @@ def test_bond_counts_and_energy_offset():
     r = O.Replica(m, 512, 4, 3, 0)
     r.timesteps(200, 2.0)
     assert sum(r.bond_count(b) for b in range(m.nbonds)) == r.n
+
+
+def test_rvb_helper_known_answers():
+    # src/sse/qmc_traits/rvb.rs:1228-1260 (find_overlapping_starts) and src/util/vec_help.rs (remove_doubles)
+    flips = [0, 2, 4, 6, 8]
+    assert O.find_overlapping_starts(1, 7, 10, flips) == [0, 1, 2, 3]
+    assert O.find_overlapping_starts(5, 7, 10, flips) == [2, 3]
+    assert O.find_overlapping_starts(7, 1, 10, flips) == [3, 4, 0]
+    assert O.remove_doubles([0, 1, 1, 2]) == [0, 2]
+    assert O.remove_doubles([1, 1, 2, 3, 3, 3, 4]) == [2, 3, 4]
+    assert O.remove_doubles([5, 5]) == []
+    assert O.remove_doubles([]) == []
+
+
+def test_rvb_hand_built_opstrings_stay_valid():
+    # tests/check_rvb_crash.rs:68-293 style: hand-built op-strings on 2 variables, 100 RVB updates each, verify().
+    m = O.Model(2, [[0, 1]], [1.0], 1.0, 0.0)
+    tb = lambda v: 1 + v
+    strings = [
+        [O.op_make(tb(0), 0, 0), O.op_make(tb(0), 0, 1), O.op_make(0, 1, 1), O.op_make(tb(1), 0, 0), O.op_make(tb(0), 1, 0)],
+        [O.op_make(0, 2, 2), 0, O.op_make(tb(1), 1, 0), O.op_make(0, 0, 0)[0:0] if False else 0, O.op_make(tb(1), 0, 1)],
+        [O.op_make(tb(0), 0, 0)] * 3 + [O.op_make(tb(1), 0, 0)] * 3,
+    ]
+    states = [[0, 0], [0, 1], [0, 0]]
+    for words, st in zip(strings, states):
+        for seed in range(6):
+            r = O.Replica(m, 64, len(words), seed, 0, st)
+            r.set_ops(words)
+            assert r.verify()
+            n0 = r.n
+            for _ in range(100):
+                r.rvb_update(1)
+                assert r.verify()
+            assert r.n == n0  # RVB moves and rotates ops, it never changes their number
