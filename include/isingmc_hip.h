@@ -85,6 +85,9 @@ int isingmc_diagonal_update(isingmc_batch *b, const double *beta, uint32_t flags
 int isingmc_cluster_update(isingmc_batch *b, double prob, uint32_t *n_clusters);
 /* LoopUpdater::make_loop_update_with_rng (qmc_traits/directed_loop.rs:103-171); lengths[R] may be NULL. */
 int isingmc_loop_update(isingmc_batch *b, uint32_t *lengths);
+/* RvbUpdater::rvb_update_with_ising_weight (qmc_traits/rvb.rs:88-290) as QmcIsingGraph::single_rvb_sweep drives it
+ * (qmc_ising.rs:323-418): `updates` attempts per replica (0 = (N+1)/2); successes[R] may be NULL. */
+int isingmc_rvb_update(isingmc_batch *b, uint32_t updates, uint32_t *successes);
 /* qmc_ising.rs:780-784 / Qmc::flip_free_bits (qmc_runner.rs:241-255) */
 int isingmc_flip_free_spins(isingmc_batch *b);
 /* QmcStepper::timesteps_measure_with_self (qmc_traits/qmc_stepper.rs:133-162) over

@@ -49,6 +49,7 @@ SYMBOLS = {
     "isingmc_diagonal_update": (C.c_int, [_vp, _P(_f64), _u32]),
     "isingmc_cluster_update": (C.c_int, [_vp, _f64, _P(_u32)]),
     "isingmc_loop_update": (C.c_int, [_vp, _P(_u32)]),
+    "isingmc_rvb_update": (C.c_int, [_vp, _u32, _P(_u32)]),
     "isingmc_flip_free_spins": (C.c_int, [_vp]),
     "isingmc_timesteps": (C.c_int, [_vp, _u64, _P(_f64), _u32, _u32]),
     "isingmc_get_accumulators": (C.c_int, [_vp, _P(_u64)]),
@@ -220,6 +221,13 @@ class QmcIsingGraph:
         if flip_free:
             self._check(self._lib.isingmc_flip_free_spins(self._h))
         return out
+
+    def single_rvb_sweep(self, updates_in_sweep=None):
+        """qmc_ising.rs:323-418: returns (successes per replica, attempts)."""
+        upd = (self.nvars + 1) // 2 if updates_in_sweep is None else int(updates_in_sweep)
+        out = np.zeros(self.nreplicas, dtype=np.uint32)
+        self._check(self._lib.isingmc_rvb_update(self._h, upd, _ptr(out, C.c_uint32)))
+        return out, upd
 
     def loop_update(self):
         out = np.zeros(self.nreplicas, dtype=np.uint32)

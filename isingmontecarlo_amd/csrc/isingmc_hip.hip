@@ -19,6 +19,7 @@ struct isingmc_batch {
     uint32_t W = 8, K = 4, CL = 0;
     uint64_t steps_per_launch = 0;
     uint32_t acc_rows = 0;
+    uint32_t rvb_updates = 0;
     uint32_t *d_acc_row = nullptr;
     size_t lds_bytes = 0;
     int device = 0;
@@ -134,6 +135,11 @@ static int check_errors(isingmc_batch *b) {
                 b->err = buf;
                 return ISINGMC_ECAPACITY;
             }
+            if (err[r] == 6u || err[r] == 7u || err[r] == 5u) {
+                snprintf(buf, sizeof buf, "replica %u: RVB working set exceeds the LDS scratch (code %u)", r, err[r]);
+                b->err = buf;
+                return ISINGMC_ECAPACITY;
+            }
             snprintf(buf, sizeof buf, "replica %u: device integrity error %u", r, err[r]);
             b->err = buf;
             return ISINGMC_EINTEGRITY;
@@ -160,6 +166,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     A.domask = domask & 0xFFFFu;
     A.prob = prob;
     A.out_u32 = out_host ? b->d_out : nullptr;
+    A.rvb_updates = b->rvb_updates;
     LaunchCfg lc{};
     lc.W = b->W; lc.K = b->K; lc.CL = b->CL; lc.phase = (domask >> 16) & 1u; lc.lds_bytes = b->lds_bytes; lc.stream = b->stream;
     const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;
@@ -280,6 +287,13 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     D.lds_ufcap = (uint32_t)ufcap;
     b->W = W; b->K = K; b->CL = CL ? 1u : 0u;
     b->lds_bytes = 4 * (fixed + ufcap + 2 * ((ufcap + 31) / 32));
+    { // the RVB pass reuses everything from the scan tables on: make sure its scratch and constant-op table fit
+        const size_t o_cur = fixed - ((size_t)W * D.N + 1) / 2;
+        const size_t want = 4 * (o_cur + 2 + rvb_fixed_words(D.N, D.E) + (size_t)D.cap);
+        const size_t capped = want < (size_t)max_lds ? want : (size_t)max_lds;
+        if (capped > b->lds_bytes) b->lds_bytes = capped & ~(size_t)7;
+    }
+    D.lds_words = (uint32_t)(b->lds_bytes / 4);
     D.gamma = cfg->transverse; D.wh = 2.0 * std::fabs(cfg->longitudinal); D.hpos = cfg->longitudinal > 0.0 ? 1u : 0u;
 
     int rc;
@@ -320,6 +334,22 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         if (hipMemcpy(dew, ew.data(), sizeof(double) * D.E, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(dce, ce.data(), sizeof(uint32_t) * D.E, hipMemcpyHostToDevice) != hipSuccess) { b->err = "edge table upload failed"; return fail(ISINGMC_ENODEVICE); }
         D.edge_w = dew; D.edges_compact = dce;
+    }
+    { // bonds_for_var (make_classical_bonds, qmc_ising.rs:421-432): edge order
+        std::vector<uint32_t> as(D.N + 2, 0u), ad(2 * (size_t)D.E + 1), fill(D.N, 0u);
+        for (uint32_t e = 0; e < D.E; ++e) { as[cfg->edges[2 * e] + 1]++; as[cfg->edges[2 * e + 1] + 1]++; }
+        for (uint32_t v = 0; v < D.N; ++v) as[v + 1] += as[v];
+        for (uint32_t e = 0; e < D.E; ++e) {
+            const uint32_t a = cfg->edges[2 * e], c2 = cfg->edges[2 * e + 1];
+            ad[as[a] + fill[a]++] = e;
+            ad[as[c2] + fill[c2]++] = e;
+        }
+        uint32_t *das = nullptr, *dad = nullptr;
+        if ((rc = dalloc(b, &das, D.N + 2, false))) return fail(rc);
+        if ((rc = dalloc(b, &dad, 2 * (size_t)D.E + 1, false))) return fail(rc);
+        if (hipMemcpy(das, as.data(), sizeof(uint32_t) * (D.N + 2), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dad, ad.data(), sizeof(uint32_t) * (2 * (size_t)D.E + 1), hipMemcpyHostToDevice) != hipSuccess) { b->err = "adjacency upload failed"; return fail(ISINGMC_ENODEVICE); }
+        D.adj_start = das; D.adj = dad;
     }
     const size_t ufstride = ids_max + 2 * ((ids_max + 31) / 32);
     if ((rc = dalloc(b, &D.uf_scratch, (size_t)D.R * ufstride, false))) return fail(rc);
@@ -371,14 +401,24 @@ int isingmc_loop_update(isingmc_batch *b, uint32_t *lengths) {
     if (b && !lengths) { tmp.resize(b->dev.R); lengths = tmp.data(); }
     return run(b, nullptr, 1, 0, SSE_DO_LOOP, 0.5, lengths);
 }
+int isingmc_rvb_update(isingmc_batch *b, uint32_t updates, uint32_t *successes) {
+    if (!b) return ISINGMC_EINVAL;
+    std::vector<uint32_t> tmp;
+    if (!successes) { tmp.resize(b->dev.R); successes = tmp.data(); }
+    b->rvb_updates = updates;
+    const int rc = run(b, nullptr, 1, 0, SSE_DO_RVB, 0.5, successes);
+    b->rvb_updates = 0;
+    return rc;
+}
 int isingmc_flip_free_spins(isingmc_batch *b) { return run(b, nullptr, 1, 0, SSE_DO_FREE, 0.5, nullptr); }
 
 int isingmc_timesteps(isingmc_batch *b, uint64_t t, const double *beta, uint32_t sampling_freq, uint32_t flags) {
     if (!b) return ISINGMC_EINVAL;
-    if (flags & ISINGMC_FLAG_RVB) { b->err = "RVB updates are not implemented in this build"; return ISINGMC_ENOTIMPL; }
+    b->rvb_updates = 0;
     uint32_t m = SSE_DO_DIAG | SSE_DO_GROW | SSE_DO_FREE;
     if (flags & ISINGMC_FLAG_HEATBATH) m |= SSE_DO_HEATBATH;
     if (flags & ISINGMC_FLAG_LOOP) m |= SSE_DO_LOOP;
+    if (flags & ISINGMC_FLAG_RVB) m |= SSE_DO_RVB;
     if (!(flags & ISINGMC_FLAG_NO_CLUSTER)) m |= SSE_DO_CLUSTER;
     if (flags & ISINGMC_FLAG_PREP) m |= 0x10000u;
     if (sampling_freq == 0) sampling_freq = 1; // qmc_stepper.rs:147 unwrap_or(1)

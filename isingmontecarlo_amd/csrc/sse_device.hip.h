@@ -54,6 +54,8 @@ struct DevBatch {
     uint32_t *uf_scratch; // [R][W*N+cap (+bit arrays)] union-find fallback in HBM
     uint32_t seed_lo, seed_hi, replica_offset;
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
+    uint32_t lds_words;   // dynamic LDS words available to the workgroup
+    const uint32_t *adj_start, *adj; // [N+1], [2E] bonds_for_var (make_classical_bonds, qmc_ising.rs:421-432)
     unsigned long long *dbg; // [R][16] phase durations in 10-ns ticks (diagnostic builds only, -DSSE_PHASE_TIMING)
 };
 
@@ -72,6 +74,7 @@ struct DevBatch {
 #define SSE_DO_FREE 8u
 #define SSE_DO_GROW 16u
 #define SSE_DO_HEATBATH 32u
+#define SSE_DO_RVB 64u
 
 struct SweepArgs {
     const double *beta; // [R]
@@ -80,7 +83,8 @@ struct SweepArgs {
     uint32_t sampling_freq; // 0 = never sample
     uint32_t domask;
     double prob;
-    uint32_t *out_u32; // optional per-replica output (n_clusters / loop length) of the LAST step
+    uint32_t rvb_updates; // RVB attempts per step (0 = (N+1)/2, qmc_ising.rs:711)
+    uint32_t *out_u32; // optional per-replica output (n_clusters / loop length / RVB successes) of the LAST step
 };
 
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -894,6 +898,10 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
     return visited;
 }
 
+} // namespace sse
+#include "sse_rvb.hip.h"
+namespace sse {
+
 // ---------------------------------------------------------------------------------------------
 // One launch = nsteps timesteps of every replica.  Reference drivers: QmcIsingGraph::timestep
 // (qmc_ising.rs:644-795), Qmc::timestep (qmc_runner.rs:363-377), measurement loop
@@ -929,6 +937,13 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
                 const uint32_t want = (uint32_t)n + (uint32_t)n / 2u;
                 if (want > M) { if (want > B.cap) { err = 1u; break; } M = want; }
             }
+        }
+        if (A.domask & SSE_DO_RVB) { // qmc_ising.rs:705-752
+            const uint32_t updates = A.rvb_updates ? A.rvb_updates : (B.N + 1u) / 2u;
+            last_out = rvb_pass<W, CL>(B, L, r, epoch, M, updates, gr, err);
+            epoch++;
+            a4 += updates;
+            if (err) break;
         }
         if (A.domask & SSE_DO_LOOP) {
             const Rng rng = make_rng(B, r, epoch);

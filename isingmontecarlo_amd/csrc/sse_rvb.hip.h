@@ -1,0 +1,794 @@
+// sse_rvb.hip.h — resonating-valence-bond update on gfx950 (included by sse_device.hip.h).
+//
+// Reference: RvbUpdater::rvb_update_with_ising_weight (src/sse/qmc_traits/rvb.rs:88-290) with build_cluster
+// (:1054-1123), find_overlapping_starts (:1125-1158), find_constants (:1160-1187), calculate_flip_prob
+// (:649-946), calculate_mult (:1194-1220), mutate_graph (:294-615), WeightedBoundaryManager (:967-1052) and
+// BondContainer (src/util/bondcontainer.rs).
+//
+// The update is a chain of `updates` dependent attempts, each touching a handful of variables inside a few
+// imaginary-time windows.  The reference walks per-variable linked lists (fast_ops.rs:1027-1172, :669-774);
+// here the workgroup GATHERS what a window needs straight from the op-string:
+//   * find_constants        -> workgroup counting sort of the transverse-op positions by variable (LDS);
+//   * ops touching the sub-variables inside a window -> cooperative scan with wave64 ballot + prefix-sum
+//     compaction into an LDS list, in p order, in batches;
+//   * the state of the sub-variables at a window start -> cooperative backward search for the last op on
+//     each of them;
+// and one lane then replays the (short) sequential rule over the gathered list.  All scratch lives in the LDS
+// region that the cluster pass uses for its union-find (the two passes never overlap).
+#pragma once
+
+namespace sse {
+
+#define SSE_RVB_MAXSUB 512u    // sub-variables (cluster + boundary) of one attempt
+#define SSE_RVB_MAXCL 72u      // cluster members (trailing_ones(u64)+1 <= 65)
+#define SSE_RVB_SETCAP 192u    // candidates in each weighted boundary set
+#define SSE_RVB_BONDCAP 288u   // boundary bonds tracked at once
+#define SSE_RVB_GCAP 1536u     // gathered ops per batch
+#define SSE_RVB_MAXWIN 80u     // time windows of one attempt
+
+struct RvbLds { // word offsets into lds_raw
+    uint32_t o_vstart;  // [N+1]
+    uint32_t o_zero;    // [N]   variables without constant ops
+    uint32_t o_v2s;     // [N] u16: sub-variable index or 0xFFFF
+    uint32_t o_adjs;    // [N+1] u16 adjacency starts (when staged)
+    uint32_t o_adj;     // [2E] u16 adjacency (when staged)
+    uint32_t o_sub;     // [MAXSUB] variable of each sub-variable (sorted)
+    uint32_t o_sfl;     // [MAXSUB] bit0 cluster_starting_state, bit1 cluster_state, bit2 substate
+    uint32_t o_last;    // [MAXSUB] backward-search result (p+1 of the last op before a window)
+    uint32_t o_clv, o_clf; // [MAXCL]
+    uint32_t o_tog;     // [2*MAXCL]
+    uint32_t o_wfrom, o_wuntil; // [MAXWIN]
+    uint32_t o_bfk, o_bfv, o_bfw; // flips set: key (= flip index), var, weight (double = 2 words)
+    uint32_t o_bnk, o_bnw;        // no-flips set: key (= var), weight
+    uint32_t o_bk, o_bwb, o_bwa;  // boundary bonds: key, weight before, weight after
+    uint32_t o_glp, o_glw;        // gathered ops: slot, word
+    uint32_t o_ctl;     // [16] control words shared between the sequential lane and the workgroup
+    uint32_t o_cps;     // [cps_cap] constant-op positions grouped by variable
+    uint32_t cps_cap;
+    uint32_t adj_lds;
+};
+enum { RC_NSUB = 0, RC_NWIN = 1, RC_ACCEPT = 2, RC_GLEN = 3, RC_NEXTP = 4, RC_ERR = 5, RC_NZERO = 6, RC_SKIP = 7 };
+
+__device__ __forceinline__ double &ldsd(uint32_t off, uint32_t i) { return reinterpret_cast<double *>(lds_raw)[(off >> 1) + i]; }
+
+// words of RVB scratch in front of the constant-op table (mirrors rvb_carve; used by the host to size LDS)
+__host__ __device__ inline uint32_t rvb_fixed_words(uint32_t N, uint32_t E) {
+    const uint32_t adj = (N < 65535u && E < 65535u) ? (N + 2) / 2 + E : 0u;
+    return 1u + 4 * SSE_RVB_SETCAP + 4 * SSE_RVB_BONDCAP + (N + 1) + N + (N + 1) / 2 + adj + 3 * SSE_RVB_MAXSUB +
+           4 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 2 * SSE_RVB_GCAP + 16;
+}
+
+template <int W>
+__device__ __forceinline__ void rvb_carve(RvbLds &R, const Lds<W> &L, const DevBatch &B) {
+    uint32_t base = (L.o_cur + 1u) & ~1u; // even: doubles are 8-byte aligned
+    R.o_bfw = base; base += 2 * SSE_RVB_SETCAP;
+    R.o_bnw = base; base += 2 * SSE_RVB_SETCAP;
+    R.o_bwb = base; base += 2 * SSE_RVB_BONDCAP;
+    R.o_bwa = base; base += 2 * SSE_RVB_BONDCAP;
+    R.o_vstart = base; base += B.N + 1;
+    R.o_zero = base; base += B.N;
+    R.o_v2s = base; base += (B.N + 1) / 2;
+    R.adj_lds = (B.N < 65535u && B.E < 65535u) ? 1u : 0u;
+    R.o_adjs = base; base += R.adj_lds ? (B.N + 2) / 2 : 0u;
+    R.o_adj = base; base += R.adj_lds ? B.E : 0u; // 2E u16
+    R.o_sub = base; base += SSE_RVB_MAXSUB;
+    R.o_sfl = base; base += SSE_RVB_MAXSUB;
+    R.o_last = base; base += SSE_RVB_MAXSUB;
+    R.o_clv = base; base += SSE_RVB_MAXCL;
+    R.o_clf = base; base += SSE_RVB_MAXCL;
+    R.o_tog = base; base += 2 * SSE_RVB_MAXCL;
+    R.o_wfrom = base; base += SSE_RVB_MAXWIN;
+    R.o_wuntil = base; base += SSE_RVB_MAXWIN;
+    R.o_bfk = base; base += SSE_RVB_SETCAP;
+    R.o_bfv = base; base += SSE_RVB_SETCAP;
+    R.o_bnk = base; base += SSE_RVB_SETCAP;
+    R.o_bk = base; base += SSE_RVB_BONDCAP;
+    R.o_glp = base; base += SSE_RVB_GCAP;
+    R.o_glw = base; base += SSE_RVB_GCAP;
+    R.o_ctl = base; base += 16;
+    R.o_cps = base;
+    R.cps_cap = B.lds_words > base ? B.lds_words - base : 0u;
+}
+
+// ---- adjacency (bonds_for_var: make_classical_bonds, qmc_ising.rs:421-432) ----
+__device__ __forceinline__ uint32_t adj_begin(const RvbLds &R, const DevBatch &B, uint32_t v) {
+    return R.adj_lds ? (uint32_t)LDSH(R.o_adjs, v) : B.adj_start[v];
+}
+__device__ __forceinline__ uint32_t adj_at(const RvbLds &R, const DevBatch &B, uint32_t i) {
+    return R.adj_lds ? (uint32_t)LDSH(R.o_adj, i) : B.adj[i];
+}
+
+struct RvbDraw {
+    uint32_t k0, k1, replica, epoch_lo, attempt, k;
+    __device__ __forceinline__ uint4 next() {
+        return philox4x32_10(k++, epoch_lo, replica, (SSE_TAG_RVB << 24) | (attempt & 0xFFFFFFu), k0, k1);
+    }
+};
+
+// x^n by squaring: the same multiplication sequence as the oracle
+__device__ __forceinline__ double powi_sq(double x, uint32_t n) {
+    double r = 1.0;
+    while (n) { if (n & 1u) r *= x; x *= x; n >>= 1; }
+    return r;
+}
+
+// ---- weighted candidate sets of the boundary manager (sequential lane only) ----
+struct WSet {
+    uint32_t o_key, o_var, o_w; // o_var == 0xFFFFFFFF: the variable is the key
+    uint32_t n;
+    double total;
+    __device__ __forceinline__ int find(uint32_t key) const {
+        for (uint32_t i = 0; i < n; ++i) if (LDSW(o_key, i) == key) return (int)i;
+        return -1;
+    }
+    // BondContainer::insert of (existing weight + w) (rvb.rs:1044-1045)
+    __device__ __forceinline__ bool add(uint32_t key, uint32_t var, double w) {
+        const int i = find(key);
+        if (i >= 0) {
+            const double old = ldsd(o_w, i), neww = old + w;
+            total += neww - old;
+            ldsd(o_w, i) = neww;
+            return true;
+        }
+        if (n >= SSE_RVB_SETCAP) return false;
+        LDSW(o_key, n) = key;
+        if (o_var != 0xFFFFFFFFu) LDSW(o_var, n) = var;
+        const double neww = 0.0 + w;
+        ldsd(o_w, n) = neww;
+        total += neww;
+        n++;
+        return true;
+    }
+    __device__ __forceinline__ void remove_at(uint32_t i) { // swap-remove (bondcontainer.rs:55-72)
+        const double w = ldsd(o_w, i);
+        const uint32_t last = n - 1;
+        LDSW(o_key, i) = LDSW(o_key, last);
+        if (o_var != 0xFFFFFFFFu) LDSW(o_var, i) = LDSW(o_var, last);
+        ldsd(o_w, i) = ldsd(o_w, last);
+        n--;
+        total -= w;
+        if (total < 0.0) total = 0.0;
+    }
+    __device__ __forceinline__ uint32_t pick(double u) const { // bondcontainer.rs:29-45
+        double p = u * total;
+        uint32_t i = 0;
+        while (i < n) {
+            p -= ldsd(o_w, i);
+            if (p <= 0.0) break;
+            i++;
+        }
+        return i < n ? i : n - 1;
+    }
+};
+
+// ---- boundary-bond sets: one key list, weights before / after the flip ----
+struct BSet {
+    uint32_t o_key, o_wb, o_wa;
+    uint32_t n;
+    double tb, ta;
+    __device__ __forceinline__ int find(uint32_t key) const {
+        for (uint32_t i = 0; i < n; ++i) if (LDSW(o_key, i) == key) return (int)i;
+        return -1;
+    }
+    __device__ __forceinline__ bool insert(uint32_t key, double wb, double wa) {
+        const int i = find(key);
+        if (i >= 0) {
+            tb += wb - ldsd(o_wb, i); ldsd(o_wb, i) = wb;
+            ta += wa - ldsd(o_wa, i); ldsd(o_wa, i) = wa;
+            return true;
+        }
+        if (n >= SSE_RVB_BONDCAP) return false;
+        LDSW(o_key, n) = key; ldsd(o_wb, n) = wb; ldsd(o_wa, n) = wa;
+        tb += wb; ta += wa;
+        n++;
+        return true;
+    }
+    __device__ __forceinline__ void remove(uint32_t key) {
+        const int i = find(key);
+        if (i < 0) return;
+        const double wb = ldsd(o_wb, i), wa = ldsd(o_wa, i);
+        const uint32_t last = n - 1;
+        LDSW(o_key, i) = LDSW(o_key, last); ldsd(o_wb, i) = ldsd(o_wb, last); ldsd(o_wa, i) = ldsd(o_wa, last);
+        n--;
+        tb -= wb; if (tb < 0.0) tb = 0.0;
+        ta -= wa; if (ta < 0.0) ta = 0.0;
+    }
+    __device__ __forceinline__ uint32_t pick_before(double u) const {
+        double p = u * tb;
+        uint32_t i = 0;
+        while (i < n) {
+            p -= ldsd(o_wb, i);
+            if (p <= 0.0) break;
+            i++;
+        }
+        return i < n ? i : n - 1;
+    }
+};
+
+__device__ __forceinline__ uint32_t v2s_get(const RvbLds &R, uint32_t v) { return (uint32_t)LDSH(R.o_v2s, v); }
+
+// two-site diagonal weight of edge b for spins (sa, sb) (qmc_ising.rs:382-385 -> :863-875)
+template <bool CL, int W>
+__device__ __forceinline__ double rvb_edge_w(const DevBatch &B, const Lds<W> &L, uint32_t b, uint32_t sa, uint32_t sb, Bd *out = nullptr) {
+    const Bd d = decode_bond<CL, W>(B, L, b);
+    if (out) *out = d;
+    const uint32_t s = (sa & 1u) | ((sb & 1u) << 1);
+    return bond_weight(d, s, s);
+}
+
+// the "Now update bonds" block of calculate_flip_prob (rvb.rs:901-934) and mutate_graph (:560-592) for one variable
+template <bool CL, int W>
+__device__ __forceinline__ bool rvb_update_bonds(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t v, BSet &bs, bool with_after) {
+    const uint32_t sv = v2s_get(R, v);
+    if (sv == 0xFFFFu) return true;
+    const uint32_t i1 = adj_begin(R, B, v + 1);
+    for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
+        const uint32_t b = adj_at(R, B, i);
+        const Bd d = decode_bond<CL, W>(B, L, b);
+        const uint32_t ov = d.a == v ? d.c : d.a;
+        const uint32_t so = v2s_get(R, ov);
+        if (so == 0xFFFFu) continue;
+        const uint32_t fv = LDSW(R.o_sfl, sv), fo = LDSW(R.o_sfl, so);
+        if (((fv ^ fo) & 2u) == 0u) {
+            bs.remove(b);
+        } else {
+            const uint32_t sa = v2s_get(R, d.a), sb = v2s_get(R, d.c);
+            uint32_t ba = (LDSW(R.o_sfl, sa) >> 2) & 1u, bb = (LDSW(R.o_sfl, sb) >> 2) & 1u;
+            const uint32_t s0 = ba | (bb << 1);
+            const double wbef = bond_weight(d, s0, s0);
+            double waft = 0.0;
+            if (with_after) { // ws_for_flip (:665-683): flip the variable that is inside the cluster
+                const uint32_t flipsub = (fv & 2u) ? sv : so;
+                if (flipsub == sa) ba ^= 1u; else bb ^= 1u;
+                const uint32_t s1 = ba | (bb << 1);
+                waft = bond_weight(d, s1, s1);
+            }
+            if (!bs.insert(b, wbef, waft)) return false;
+        }
+    }
+    return true;
+}
+
+// set_initial_bonds (rvb.rs:617-645) / the initial fill of mutate_graph (:366-380)
+template <bool CL, int W>
+__device__ __forceinline__ bool rvb_initial_bonds(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t nsub, BSet &bs, bool with_after) {
+    for (uint32_t s = 0; s < nsub; ++s) {
+        if (!(LDSW(R.o_sfl, s) & 2u)) continue;
+        const uint32_t v = LDSW(R.o_sub, s);
+        const uint32_t i1 = adj_begin(R, B, v + 1);
+        for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
+            const uint32_t b = adj_at(R, B, i);
+            const Bd d = decode_bond<CL, W>(B, L, b);
+            const uint32_t ov = d.a == v ? d.c : d.a;
+            const uint32_t so = v2s_get(R, ov);
+            if (so == 0xFFFFu || (LDSW(R.o_sfl, so) & 2u)) continue;
+            const uint32_t sa = v2s_get(R, d.a), sb = v2s_get(R, d.c);
+            uint32_t ba = (LDSW(R.o_sfl, sa) >> 2) & 1u, bb = (LDSW(R.o_sfl, sb) >> 2) & 1u;
+            const uint32_t s0 = ba | (bb << 1);
+            const double wbef = bond_weight(d, s0, s0);
+            double waft = 0.0;
+            if (with_after) {
+                if (s == sa) ba ^= 1u; else bb ^= 1u;
+                const uint32_t s1 = ba | (bb << 1);
+                waft = bond_weight(d, s1, s1);
+            }
+            if (!bs.insert(b, wbef, waft)) return false;
+        }
+    }
+    return true;
+}
+
+// find_overlapping_starts (rvb.rs:1125-1158) over cps[fp0 .. fp0+Lf); calls f(index) for each overlapping segment
+template <typename F>
+__device__ __forceinline__ void rvb_overlaps(const RvbLds &R, uint32_t p_start, uint32_t p_end, uint32_t cutoff, uint32_t fp0, uint32_t Lf, F f) {
+    uint32_t bin = 0;
+    while (bin < Lf && LDSW(R.o_cps, fp0 + bin) < p_start) bin++;
+    const uint32_t prev = (bin + Lf - 1) % Lf;
+    const uint32_t lowest = LDSW(R.o_cps, fp0 + prev);
+    const uint32_t off_start = (p_start + cutoff - lowest) % cutoff, off_end = (p_end + cutoff - lowest) % cutoff;
+    for (uint32_t step = 0; step < Lf; ++step) {
+        const uint32_t ip = (prev + step) % Lf;
+        const uint32_t p = LDSW(R.o_cps, fp0 + ip);
+        const uint32_t check_start = (p + cutoff - lowest) % cutoff;
+        const uint32_t next_p = LDSW(R.o_cps, fp0 + (ip + 1) % Lf);
+        const uint32_t check_end = (next_p + cutoff - lowest) % cutoff;
+        const bool has_overlap_start = check_start < off_start && off_start < check_end;
+        const bool has_start_within = off_start < check_start && check_start < off_end;
+        const bool eq = (p_start == p_end) || (check_start == check_end);
+        if (!(eq || has_overlap_start || has_start_within)) break;
+        f(ip);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cooperative pieces
+
+// find_constants (rvb.rs:1160-1187): counting sort of the transverse-op positions by variable.
+// Returns C (number of constant ops) or 0xFFFFFFFF when the table does not fit in LDS.
+template <int W, bool CL>
+__device__ __forceinline__ uint32_t rvb_find_constants(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t M) {
+    constexpr int NT = W * 64;
+    const int tid = threadIdx.x;
+    const uint32_t N = B.N;
+    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    for (uint32_t v = tid; v < N; v += NT) { LDSW(R.o_zero, v) = 0u; LDSH(R.o_v2s, v) = (uint16_t)0xFFFFu; }
+    if (R.adj_lds) {
+        for (uint32_t v = tid; v <= N; v += NT) LDSH(R.o_adjs, v) = (uint16_t)B.adj_start[v];
+        for (uint32_t i = tid; i < 2 * B.E; i += NT) LDSH(R.o_adj, i) = (uint16_t)B.adj[i];
+    }
+    __syncthreads();
+    // per-variable counts (temporarily in o_zero)
+    for (uint32_t p = tid; p < M; p += NT) {
+        const uint32_t wd = ops[p];
+        if (!wd) continue;
+        const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
+        if (bd_kind(d) == SSE_BOND_TRANSVERSE) atomicAdd(&LDSW(R.o_zero, d.a), 1u);
+    }
+    __syncthreads();
+    // exclusive prefix by one lane (N is small next to M); the counts array becomes the list of variables without
+    // constant ops: entry nz <= v is written only after entry v has been read
+    if (tid == 0) {
+        uint32_t run = 0, nz = 0;
+        for (uint32_t v = 0; v < N; ++v) {
+            const uint32_t c = LDSW(R.o_zero, v);
+            LDSW(R.o_vstart, v) = run;
+            if (c == 0u) LDSW(R.o_zero, nz++) = v;
+            run += c;
+        }
+        LDSW(R.o_vstart, N) = run;
+        LDSW(R.o_ctl, RC_NZERO) = nz;
+    }
+    __syncthreads();
+    const uint32_t C = LDSW(R.o_vstart, N);
+    if (C > R.cps_cap) return 0xFFFFFFFFu;
+    // fill: vstart[v] doubles as the cursor and ends at the old vstart[v+1]; shift it back afterwards
+    for (uint32_t p = tid; p < M; p += NT) {
+        const uint32_t wd = ops[p];
+        if (!wd) continue;
+        const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
+        if (bd_kind(d) == SSE_BOND_TRANSVERSE) LDSW(R.o_cps, atomicAdd(&LDSW(R.o_vstart, d.a), 1u)) = p;
+    }
+    __syncthreads();
+    // vstart[v+1] := cursor[v], highest block first so that every element is read before it is overwritten
+    for (int64_t v0 = (int64_t)((N - 1) / NT) * NT; v0 >= 0; v0 -= NT) {
+        const uint32_t v = (uint32_t)v0 + tid;
+        const uint32_t x = v < N ? LDSW(R.o_vstart, v) : 0u;
+        __syncthreads();
+        if (v < N) LDSW(R.o_vstart, v + 1) = x;
+        __syncthreads();
+    }
+    if (tid == 0) LDSW(R.o_vstart, 0) = 0u;
+    __syncthreads();
+    for (uint32_t v = tid; v < N; v += NT) { // insertion sort: the lists hold ~ beta*Gamma entries each
+        const uint32_t s = LDSW(R.o_vstart, v), e = LDSW(R.o_vstart, v + 1);
+        for (uint32_t i = s + 1; i < e; ++i) {
+            const uint32_t x = LDSW(R.o_cps, i);
+            uint32_t j = i;
+            while (j > s && LDSW(R.o_cps, j - 1) > x) { LDSW(R.o_cps, j) = LDSW(R.o_cps, j - 1); j--; }
+            LDSW(R.o_cps, j) = x;
+        }
+    }
+    __syncthreads();
+    return C;
+}
+
+// Gather the ops of slots [gp, until] that touch a sub-variable, in p order, into the LDS list (one batch).
+// Returns through RC_GLEN / RC_NEXTP (slot to resume from, until+1 when the window is exhausted).
+template <int W, bool CL>
+__device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t gp, uint32_t until,
+                                           uint32_t M, uint32_t &gr) {
+    constexpr int NT = W * 64;
+    constexpr int U = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    const uint32_t last = until < M ? until : M - 1; // inclusive
+    uint32_t glen = 0, next = gp;
+    while (M != 0u && next <= last) {
+        uint32_t wd[U];
+        uint64_t mm[U];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t p = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
+            wd[j] = p <= last ? ops[p] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            bool match = false;
+            if (wd[j]) {
+                const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
+                match = v2s_get(R, d.a) != 0xFFFFu || (d.c != SSE_NO_VAR && v2s_get(R, d.c) != 0xFFFFu);
+            }
+            mm[j] = __ballot(match);
+            cnt += popc64(mm[j]);
+        }
+        const int buf = gr & 1;
+        if (lane == 0) LDSI(L.o_tot, buf * W + wave) = cnt;
+        __syncthreads();
+        gr++;
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2); if (w2 < wave) wbase += t; total += t; }
+        if (glen + total > SSE_RVB_GCAP) {
+            if (glen == 0) { if (tid == 0) LDSW(R.o_ctl, RC_ERR) = 5u; next = last + 1; }
+            break; // this chunk goes to the next batch
+        }
+        uint32_t run = glen + wbase;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if ((mm[j] >> lane) & 1ull) {
+                const uint32_t idx = run + popc64(mm[j] & lanemask_lt(lane));
+                LDSW(R.o_glp, idx) = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
+                LDSW(R.o_glw, idx) = wd[j];
+            }
+            run += popc64(mm[j]);
+        }
+        glen += total;
+        next += U * NT;
+    }
+    __syncthreads();
+    if (tid == 0) { LDSW(R.o_ctl, RC_GLEN) = glen; LDSW(R.o_ctl, RC_NEXTP) = (M == 0u || next > last) ? last + 1 : next; }
+    __syncthreads();
+}
+
+// get_propagated_substate_with_hint (fast_ops.rs:1027-1172): the spin of every sub-variable just before slot `from`
+// = the output bit of its last op in [0, from), else the p=0 state.  Cooperative backward search.
+template <int W, bool CL>
+__device__ __forceinline__ void rvb_state_at(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t from, uint32_t nsub,
+                                             bool flip_by_cluster) {
+    constexpr int NT = W * 64;
+    constexpr int U = 4;
+    const int tid = threadIdx.x;
+    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    for (uint32_t s = tid; s < nsub; s += NT) LDSW(R.o_last, s) = 0u;
+    if (tid == 0) LDSW(R.o_ctl, RC_SKIP) = 0u;
+    __syncthreads();
+    uint32_t hi = from; // search slots [lo, hi)
+    while (hi > 0) {
+        const uint32_t span = (uint32_t)(U * NT);
+        const uint32_t lo = hi > span ? hi - span : 0u;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t p = lo + (uint32_t)(j * NT + tid);
+            if (p < hi) {
+                const uint32_t wd = ops[p];
+                if (wd) {
+                    const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
+                    const uint32_t sa = v2s_get(R, d.a);
+                    if (sa != 0xFFFFu) atomicMax(&LDSW(R.o_last, sa), ((p + 1u) << 1) | (sse_op_out(wd) & 1u));
+                    if (d.c != SSE_NO_VAR) {
+                        const uint32_t sc = v2s_get(R, d.c);
+                        if (sc != 0xFFFFu) atomicMax(&LDSW(R.o_last, sc), ((p + 1u) << 1) | ((sse_op_out(wd) >> 1) & 1u));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // all found?
+        uint32_t missing = 0;
+        for (uint32_t s = tid; s < nsub; s += NT) missing |= (LDSW(R.o_last, s) == 0u);
+        if (missing) LDSW(R.o_ctl, RC_SKIP) = 1u;
+        __syncthreads();
+        const uint32_t any = LDSW(R.o_ctl, RC_SKIP);
+        __syncthreads();
+        if (tid == 0) LDSW(R.o_ctl, RC_SKIP) = 0u;
+        hi = lo;
+        if (!any) break;
+    }
+    __syncthreads();
+    for (uint32_t s = tid; s < nsub; s += NT) {
+        const uint32_t x = LDSW(R.o_last, s);
+        const uint32_t v = LDSW(R.o_sub, s);
+        uint32_t bit = x ? (x & 1u) : ((LDSW(L.o_state, v >> 5) >> (v & 31)) & 1u);
+        uint32_t f = LDSW(R.o_sfl, s);
+        if (flip_by_cluster) bit ^= (f >> 1) & 1u;
+        LDSW(R.o_sfl, s) = (f & 3u) | (bit << 2);
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int W, bool CL>
+__device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, uint64_t epoch, uint32_t M, uint32_t updates,
+                                             uint32_t &gr, uint32_t &err) {
+    const int tid = threadIdx.x;
+    const uint32_t N = B.N;
+    uint32_t *ops = B.ops + (size_t)r * B.cap;
+    RvbLds R;
+    rvb_carve<W>(R, L, B);
+    if (tid == 0) LDSW(R.o_ctl, RC_ERR) = 0u;
+    __syncthreads();
+    const uint32_t C = rvb_find_constants<W, CL>(B, L, R, r, M);
+    if (C == 0xFFFFFFFFu) { err = 6u; return 0u; } // constant-op table does not fit in LDS
+    const uint32_t nzero = LDSW(R.o_ctl, RC_NZERO);
+    uint32_t nsucc = 0;
+
+    for (uint32_t attempt = 0; attempt < updates; ++attempt) {
+        RvbDraw g;
+        g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.replica_offset + r; g.epoch_lo = (uint32_t)epoch; g.attempt = attempt; g.k = 0;
+        // ================= phase A (sequential lane): start, cluster growth, sub-variables, windows =================
+        if (tid == 0) {
+            uint32_t lerr = 0;
+            uint4 o = g.next();
+            const uint32_t choice = __umulhi(o.x, C + nzero);
+            uint32_t v0, f0;
+            if (choice < C) {
+                uint32_t lo = 0, hi = N;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (LDSW(R.o_vstart, mid) <= choice) lo = mid; else hi = mid; }
+                v0 = lo; f0 = choice;
+            } else { v0 = LDSW(R.o_zero, choice - C); f0 = SSE_NO_VAR; }
+            o = g.next();
+            unsigned long long bits = (unsigned long long)o.x | ((unsigned long long)o.y << 32);
+            uint32_t csize = 1;
+            while ((bits & 1ull) && csize <= 64) { csize++; bits >>= 1; }
+            WSet bf, bn;
+            bf.o_key = R.o_bfk; bf.o_var = R.o_bfv; bf.o_w = R.o_bfw; bf.n = 0; bf.total = 0.0;
+            bn.o_key = R.o_bnk; bn.o_var = 0xFFFFFFFFu; bn.o_w = R.o_bnw; bn.n = 0; bn.total = 0.0;
+            uint32_t ncl = 0;
+            auto in_cluster = [&](uint32_t var, uint32_t pos) -> bool { // popped flags of the boundary manager (:1038-1043)
+                for (uint32_t i = 0; i < ncl; ++i) {
+                    const uint32_t cf = LDSW(R.o_clf, i);
+                    if (pos != SSE_NO_VAR ? cf == pos : (cf == SSE_NO_VAR && LDSW(R.o_clv, i) == var)) return true;
+                }
+                return false;
+            };
+            auto push_adj = [&](uint32_t var, uint32_t pos, double w) {
+                if (in_cluster(var, pos)) return;
+                const bool ok = pos != SSE_NO_VAR ? bf.add(pos, var, w) : bn.add(var, var, w);
+                if (!ok) lerr = 7u;
+            };
+            push_adj(v0, f0, 1.0);
+            uint32_t left = csize;
+            while (left > 0 && (bf.n + bn.n) > 0 && !lerr) {
+                o = g.next();
+                const double f_ratio = bf.total / (bf.total + bn.total);
+                bool pick_flips = u01(o.x) < f_ratio;
+                if (bf.n == 0) pick_flips = false;
+                if (bn.n == 0) pick_flips = true;
+                o = g.next();
+                uint32_t v, flip;
+                if (pick_flips) { const uint32_t idx = bf.pick(u01(o.x)); v = LDSW(bf.o_var, idx); flip = LDSW(bf.o_key, idx); bf.remove_at(idx); }
+                else { const uint32_t idx = bn.pick(u01(o.x)); v = LDSW(bn.o_key, idx); flip = SSE_NO_VAR; bn.remove_at(idx); }
+                if (ncl >= SSE_RVB_MAXCL) { lerr = 7u; break; }
+                LDSW(R.o_clv, ncl) = v; LDSW(R.o_clf, ncl) = flip; ncl++;
+                const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
+                if (flip != SSE_NO_VAR) {
+                    const uint32_t rel = flip - vs;
+                    push_adj(v, (rel + vl - 1) % vl + vs, 1.0);
+                    push_adj(v, (rel + 1) % vl + vs, 1.0);
+                }
+                const uint32_t i1 = adj_begin(R, B, v + 1);
+                for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
+                    const uint32_t b = adj_at(R, B, i);
+                    const Bd d = decode_bond<CL, W>(B, L, b);
+                    const double weight = d.w * 0.5; // bond_mag = |J| (qmc_ising.rs:633-635)
+                    const uint32_t ov = d.a == v ? d.c : d.a;
+                    const uint32_t os = LDSW(R.o_vstart, ov), ol = LDSW(R.o_vstart, ov + 1) - os;
+                    if (ol == 0) push_adj(ov, SSE_NO_VAR, weight);
+                    else if (flip != SSE_NO_VAR) {
+                        const uint32_t rel = flip - vs;
+                        const uint32_t finc = (rel + 1) % vl + vs;
+                        rvb_overlaps(R, LDSW(R.o_cps, flip), LDSW(R.o_cps, finc), M, os, ol, [&](uint32_t ip) { push_adj(ov, ip + os, weight); });
+                    } else {
+                        for (uint32_t pi = os; pi < os + ol; ++pi) push_adj(ov, pi, weight);
+                    }
+                }
+                left--;
+            }
+            // ---- sub-variables: sorted union of cluster and remaining boundary variables (:155-172) ----
+            uint32_t nsub = 0;
+            auto add_sub = [&](uint32_t v) { // sorted insert without duplicates
+                uint32_t i = 0;
+                while (i < nsub && LDSW(R.o_sub, i) < v) i++;
+                if (i < nsub && LDSW(R.o_sub, i) == v) return;
+                if (nsub >= SSE_RVB_MAXSUB) { lerr = 7u; return; }
+                for (uint32_t j = nsub; j > i; --j) LDSW(R.o_sub, j) = LDSW(R.o_sub, j - 1);
+                LDSW(R.o_sub, i) = v;
+                nsub++;
+            };
+            for (uint32_t i = 0; i < ncl; ++i) add_sub(LDSW(R.o_clv, i));
+            for (uint32_t i = 0; i < bf.n; ++i) add_sub(LDSW(bf.o_var, i));
+            for (uint32_t i = 0; i < bn.n; ++i) add_sub(LDSW(bn.o_key, i));
+            for (uint32_t s = 0; s < nsub; ++s) { LDSH(R.o_v2s, LDSW(R.o_sub, s)) = (uint16_t)s; LDSW(R.o_sfl, s) = 0u; }
+            // ---- starting state and toggle positions (:174-196), sort, remove_doubles (:230-231) ----
+            uint32_t ntog = 0;
+            for (uint32_t i = 0; i < ncl && !lerr; ++i) {
+                const uint32_t v = LDSW(R.o_clv, i), fi = LDSW(R.o_clf, i);
+                const uint32_t sv = v2s_get(R, v);
+                if (fi != SSE_NO_VAR) {
+                    const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
+                    uint32_t t0 = LDSW(R.o_cps, fi), t1;
+                    if (fi - vs + 1 >= vl) { LDSW(R.o_sfl, sv) |= 1u; t1 = LDSW(R.o_cps, vs); }
+                    else t1 = LDSW(R.o_cps, fi + 1);
+                    for (int q = 0; q < 2; ++q) { // sorted insert
+                        const uint32_t x = q ? t1 : t0;
+                        uint32_t j = ntog;
+                        while (j > 0 && LDSW(R.o_tog, j - 1) > x) { LDSW(R.o_tog, j) = LDSW(R.o_tog, j - 1); j--; }
+                        LDSW(R.o_tog, j) = x;
+                        ntog++;
+                    }
+                } else LDSW(R.o_sfl, sv) |= 1u;
+            }
+            { // remove_doubles (util/vec_help.rs:4-24)
+                uint32_t ii = 0, jj = 0;
+                while (jj + 1 < ntog) {
+                    if (LDSW(R.o_tog, jj) == LDSW(R.o_tog, jj + 1)) jj += 2;
+                    else { LDSW(R.o_tog, ii++) = LDSW(R.o_tog, jj++); }
+                }
+                if (jj < ntog) LDSW(R.o_tog, ii++) = LDSW(R.o_tog, jj++);
+                ntog = ii;
+            }
+            // ---- windows where the cluster is non-empty (mutate_graph :310-360); cluster_state := starting state ----
+            uint32_t count = 0, nwin = 0, nuntil = 0;
+            for (uint32_t s = 0; s < nsub; ++s) { const uint32_t f = LDSW(R.o_sfl, s) & 1u; LDSW(R.o_sfl, s) = f | (f << 1); count += f; }
+            if (count) LDSW(R.o_wfrom, nwin++) = 0u;
+            for (uint32_t i = 0; i < ntog && !lerr; ++i) {
+                const uint32_t p = LDSW(R.o_tog, i);
+                if (count == 0) { if (nwin >= SSE_RVB_MAXWIN) { lerr = 7u; break; } LDSW(R.o_wfrom, nwin++) = p; }
+                const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(ops[p]));
+                const uint32_t sv = v2s_get(R, d.a);
+                const uint32_t f = LDSW(R.o_sfl, sv) ^ 2u;
+                LDSW(R.o_sfl, sv) = f;
+                if (f & 2u) count++; else count--;
+                if (count == 0) LDSW(R.o_wuntil, nuntil++) = p;
+            }
+            if (count) LDSW(R.o_wuntil, nuntil++) = M;
+            // restore cluster_state = starting state for the probability pass
+            for (uint32_t s = 0; s < nsub; ++s) { const uint32_t f = LDSW(R.o_sfl, s) & 1u; LDSW(R.o_sfl, s) = f | (f << 1); }
+            LDSW(R.o_ctl, RC_NSUB) = nsub;
+            LDSW(R.o_ctl, RC_NWIN) = nwin;
+            LDSW(R.o_ctl, 8) = ntog;
+            LDSW(R.o_ctl, 9) = g.k;
+            if (lerr) LDSW(R.o_ctl, RC_ERR) = lerr;
+        }
+        __syncthreads();
+        if (LDSW(R.o_ctl, RC_ERR)) break;
+        const uint32_t nsub = LDSW(R.o_ctl, RC_NSUB), nwin = LDSW(R.o_ctl, RC_NWIN), ntog = LDSW(R.o_ctl, 8);
+        g.k = LDSW(R.o_ctl, 9);
+
+        // ================= phase B: calculate_flip_prob (rvb.rs:649-946) over the windows =================
+        double mult = 1.0;          // meaningful on the sequential lane
+        uint32_t nb = 0, next_tog = 0; // sequential lane
+        BSet bs;
+        bs.o_key = R.o_bk; bs.o_wb = R.o_bwb; bs.o_wa = R.o_bwa; bs.n = 0; bs.tb = 0.0; bs.ta = 0.0;
+        bool broke = false;
+        for (uint32_t wi = 0; wi < nwin; ++wi) {
+            const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
+            rvb_state_at<W, CL>(B, L, R, r, from, nsub, false);
+            if (tid == 0 && wi == 0 && from == 0 && !broke) {
+                if (!rvb_initial_bonds<CL, W>(B, L, R, nsub, bs, true)) LDSW(R.o_ctl, RC_ERR) = 7u;
+            }
+            uint32_t gp = from;
+            for (;;) {
+                rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+                const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
+                gp = LDSW(R.o_ctl, RC_NEXTP);
+                if (tid == 0 && !broke && !LDSW(R.o_ctl, RC_ERR)) {
+                    for (uint32_t i = 0; i < glen; ++i) {
+                        const uint32_t p = LDSW(R.o_glp, i), wd = LDSW(R.o_glw, i);
+                        const uint32_t b = sse_op_bond(wd), in = sse_op_in(wd), out = sse_op_out(wd);
+                        const Bd d = decode_bond<CL, W>(B, L, b);
+                        const uint32_t sa = v2s_get(R, d.a), sc = d.c != SSE_NO_VAR ? v2s_get(R, d.c) : 0xFFFFu;
+                        const bool is_bound = next_tog < ntog && p == LDSW(R.o_tog, next_tog);
+                        const bool offdiag = in != out;
+                        const bool a_in = sa != 0xFFFFu && (LDSW(R.o_sfl, sa) & 2u);
+                        const bool c_in = sc != 0xFFFFu && (LDSW(R.o_sfl, sc) & 2u);
+                        const bool all_in = a_in && (d.c == SSE_NO_VAR || c_in);
+                        if (b < B.E && bs.find(b) >= 0) { nb++; continue; }
+                        if (is_bound) { LDSW(R.o_sfl, sa) ^= 2u; next_tog++; }
+                        if (offdiag) {
+                            if (sa != 0xFFFFu) LDSW(R.o_sfl, sa) = (LDSW(R.o_sfl, sa) & 3u) | ((out & 1u) << 2);
+                            if (sc != 0xFFFFu) LDSW(R.o_sfl, sc) = (LDSW(R.o_sfl, sc) & 3u) | (((out >> 1) & 1u) << 2);
+                        }
+                        if (all_in) { // ising_ratio (qmc_ising.rs:722-735): 0 for a longitudinal op, else 1
+                            if (bd_kind(d) == SSE_BOND_LONGITUDINAL) mult *= 0.0;
+                            if (mult < 2.220446049250313e-16) { broke = true; break; }
+                        }
+                        if (offdiag || is_bound) {
+                            if (!(nb == 0 || fabs(bs.tb - bs.ta) < 2.220446049250313e-16)) mult *= powi_sq(bs.ta / bs.tb, nb);
+                            nb = 0;
+                            if (mult < 2.220446049250313e-16) { broke = true; break; }
+                            bool ok = rvb_update_bonds<CL, W>(B, L, R, d.a, bs, true);
+                            if (ok && d.c != SSE_NO_VAR) ok = rvb_update_bonds<CL, W>(B, L, R, d.c, bs, true);
+                            if (!ok) { LDSW(R.o_ctl, RC_ERR) = 7u; break; }
+                        }
+                    }
+                }
+                if (M == 0u || gp > (until < M ? until : M - 1)) break;
+            }
+        }
+        // ================= phase C: accept (:241-246) =================
+        if (tid == 0) {
+            if (!(nb == 0 || fabs(bs.tb - bs.ta) < 2.220446049250313e-16)) mult *= powi_sq(bs.ta / bs.tb, nb);
+            const uint4 o = g.next();
+            const bool accept = (mult >= 1.0) || (u01(o.x) < mult);
+            LDSW(R.o_ctl, RC_ACCEPT) = accept ? 1u : 0u;
+            LDSW(R.o_ctl, 9) = g.k;
+        }
+        __syncthreads();
+        if (LDSW(R.o_ctl, RC_ERR)) break;
+        g.k = LDSW(R.o_ctl, 9);
+        if (LDSW(R.o_ctl, RC_ACCEPT)) {
+            // ================= phase D: mutate_graph (:294-615) =================
+            // cluster_state := starting state
+            for (uint32_t s = tid; s < nsub; s += blockDim.x) { const uint32_t f = LDSW(R.o_sfl, s) & 1u; LDSW(R.o_sfl, s) = f | (f << 1); }
+            __syncthreads();
+            bs.n = 0; bs.tb = 0.0; bs.ta = 0.0;
+            uint32_t nt2 = 0;
+            for (uint32_t wi = 0; wi < nwin; ++wi) {
+                const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
+                rvb_state_at<W, CL>(B, L, R, r, from, nsub, true); // substate ^= cluster_state (:396-399, :315-318)
+                if (tid == 0 && wi == 0 && from == 0) {
+                    if (!rvb_initial_bonds<CL, W>(B, L, R, nsub, bs, false)) LDSW(R.o_ctl, RC_ERR) = 7u;
+                }
+                uint32_t gp = from;
+                for (;;) {
+                    rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+                    const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
+                    gp = LDSW(R.o_ctl, RC_NEXTP);
+                    if (tid == 0 && !LDSW(R.o_ctl, RC_ERR)) {
+                        for (uint32_t i = 0; i < glen; ++i) {
+                            const uint32_t p = LDSW(R.o_glp, i), wd = LDSW(R.o_glw, i);
+                            const uint32_t b = sse_op_bond(wd), in = sse_op_in(wd), out = sse_op_out(wd);
+                            const Bd d = decode_bond<CL, W>(B, L, b);
+                            const uint32_t sa = v2s_get(R, d.a), sc = d.c != SSE_NO_VAR ? v2s_get(R, d.c) : 0xFFFFu;
+                            const bool at_flip = nt2 < ntog && p == LDSW(R.o_tog, nt2);
+                            if (b < B.E && bs.find(b) >= 0) {
+                                // rotate the boundary op onto a boundary bond drawn by weight (:414-432)
+                                const uint4 o = g.next();
+                                const uint32_t nbnd = LDSW(bs.o_key, bs.pick_before(u01(o.x)));
+                                const Bd nd = decode_bond<CL, W>(B, L, nbnd);
+                                const uint32_t s2 = ((LDSW(R.o_sfl, v2s_get(R, nd.a)) >> 2) & 1u) | (((LDSW(R.o_sfl, v2s_get(R, nd.c)) >> 2) & 1u) << 1);
+                                ops[p] = sse_op_make(nbnd, s2, s2);
+                                continue;
+                            }
+                            if (at_flip) {
+                                const uint32_t cs = (LDSW(R.o_sfl, sa) >> 1) & 1u;
+                                const uint32_t nin = (in & 1u) ^ cs, nout = (out & 1u) ^ (cs ^ 1u);
+                                ops[p] = sse_op_make(b, nin, nout);
+                                LDSW(R.o_sfl, sa) = ((LDSW(R.o_sfl, sa) ^ 2u) & 3u) | (nout << 2);
+                                nt2++;
+                            } else {
+                                const bool a_in = sa != 0xFFFFu && (LDSW(R.o_sfl, sa) & 2u);
+                                const bool c_in = sc != 0xFFFFu && (LDSW(R.o_sfl, sc) & 2u);
+                                if (a_in || c_in) {
+                                    const uint32_t mask = d.c != SSE_NO_VAR ? 3u : 1u;
+                                    const uint32_t nin = in ^ mask, nout = out ^ mask;
+                                    ops[p] = sse_op_make(b, nin, nout);
+                                    if (nin != nout) {
+                                        if (sa != 0xFFFFu) LDSW(R.o_sfl, sa) = (LDSW(R.o_sfl, sa) & 3u) | ((nout & 1u) << 2);
+                                        if (sc != 0xFFFFu) LDSW(R.o_sfl, sc) = (LDSW(R.o_sfl, sc) & 3u) | (((nout >> 1) & 1u) << 2);
+                                    }
+                                } else if (in != out) {
+                                    if (sa != 0xFFFFu) LDSW(R.o_sfl, sa) = (LDSW(R.o_sfl, sa) & 3u) | ((out & 1u) << 2);
+                                    if (sc != 0xFFFFu) LDSW(R.o_sfl, sc) = (LDSW(R.o_sfl, sc) & 3u) | (((out >> 1) & 1u) << 2);
+                                } else {
+                                    continue; // diagonal and untouched by the cluster (:513-514)
+                                }
+                            }
+                            bool ok = rvb_update_bonds<CL, W>(B, L, R, d.a, bs, false);
+                            if (ok && d.c != SSE_NO_VAR) ok = rvb_update_bonds<CL, W>(B, L, R, d.c, bs, false);
+                            if (!ok) { LDSW(R.o_ctl, RC_ERR) = 7u; break; }
+                        }
+                    }
+                    if (M == 0u || gp > (until < M ? until : M - 1)) break;
+                }
+            }
+            __syncthreads();
+            // p=0 state of the sub-variables that start inside the cluster (:266-274)
+            for (uint32_t s = tid; s < nsub; s += blockDim.x)
+                if (LDSW(R.o_sfl, s) & 1u) { const uint32_t v = LDSW(R.o_sub, s); atomicXor(&LDSW(L.o_state, v >> 5), 1u << (v & 31)); }
+            nsucc++;
+        }
+        __syncthreads();
+        for (uint32_t s = tid; s < nsub; s += blockDim.x) LDSH(R.o_v2s, LDSW(R.o_sub, s)) = (uint16_t)0xFFFFu;
+        __syncthreads();
+        if (LDSW(R.o_ctl, RC_ERR)) break;
+    }
+    __syncthreads();
+    if (LDSW(R.o_ctl, RC_ERR)) err = LDSW(R.o_ctl, RC_ERR);
+    __syncthreads();
+    return nsucc;
+}
+
+} // namespace sse

@@ -178,3 +178,51 @@ def test_parallel_tempering_matches_oracle(oracle):
     assert tc.verify()
     acc = tc.slot_accumulators()
     assert acc.shape == (len(betas) * K, 8) and (acc[:, 1] == 30).all()
+
+
+RVB_CASES = [
+    ("single_bond", [((0, 1), 1.0)], 1.0, 0.0, 1.0, 2),
+    ("single_bond_long", [((0, 1), 1.0)], 1.0, 1.0, 1.0, 2),
+    ("villain3", lat.two_d_periodic(3), 1.0, 0.0, 1.5, 9),
+    ("villain4", lat.two_d_periodic(4), 1.0, 0.0, 2.0, 16),
+    ("ferro8x8", lat.two_d_ferro(8), 1.0, 0.0, 3.0, 64),
+]
+
+
+@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (1, 1, 1), (4, 2, 0)])
+@pytest.mark.parametrize("name,edges,gamma,h,beta,cutoff", RVB_CASES, ids=[c[0] for c in RVB_CASES])
+def test_rvb_update_matches_oracle(oracle, name, edges, gamma, h, beta, cutoff, waves, k, cfgf):
+    """RvbUpdater::rvb_update (rvb.rs:88-290): attempt by attempt identical to the oracle (ops, state, successes)."""
+    R = 4
+    g, m, reps = make_pair(oracle, edges, gamma, h, cutoff, 8192, 1357, R, waves, k=k, cfg_flags=cfgf)
+    for it in range(10):
+        g.single_diagonal_step(beta)
+        for rep in reps:
+            rep.diagonal_update(beta)
+            want = rep.n + rep.n // 2
+            if want > rep.cutoff:
+                assert rep.set_cutoff(want) == 0
+        succ, upd = g.single_rvb_sweep()
+        for r, rep in enumerate(reps):
+            assert succ[r] == rep.rvb_update(upd), f"{name}: RVB successes differ it={it} r={r}"
+        assert_same(g, reps, f"{name} rvb it={it}")
+        g.single_cluster_step(flip_free=True)
+        for rep in reps:
+            rep.cluster_update(0.5)
+            rep.flip_free_spins()
+        assert_same(g, reps, f"{name} cluster it={it}")
+    assert g.verify().all()
+
+
+def test_rvb_fused_timesteps(oracle):
+    edges = lat.two_d_periodic(4)
+    R = 6
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 16, 8192, 8642, R)
+    g.run(30, 2.0, sampling_freq=2, flags=8)
+    for rep in reps:
+        rep.timesteps(30, 2.0, 2, 8)
+    assert_same(g, reps, "rvb fused")
+    acc = g.accumulators()
+    for r, rep in enumerate(reps):
+        assert np.array_equal(acc[r, :7], rep.accumulators()[:7])
+    assert g.verify().all()
