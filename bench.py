@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-loop", action="store_true")
+    ap.add_argument("--rvb", action="store_true", help="configs[2]: QmcIsingGraph::timestep with RVB sweeps (no directed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -97,6 +98,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     flags = 0 if args.no_loop else im.FLAG_LOOP
+    if args.rvb:
+        flags = im.FLAG_RVB
     L, R, beta = args.L, args.replicas, args.beta
     edges = lattice_edges(L)
     n_est = beta * (3 * L * L + 2.2 * L * L)
@@ -105,7 +108,7 @@ def main():
                          replica_offset=rank * R, device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k)
     # data preparation: equilibrate (cutoff growth + thermalisation), untimed.  FLAG_PREP runs the identical
     # kernel under its "data preparation" symbol so that rocprofv3 --stats averages only the measured launches.
-    g.run(args.equilibrate, beta, flags=flags | im.FLAG_PREP)
+    g.run(args.equilibrate, beta, flags=(flags & ~im.FLAG_RVB) | im.FLAG_PREP)
     # one kernel launch per sweep: a "launch" in the roofline object is one sweep of all R replicas
     g.set_steps_per_launch(1)
     if args.warmup:
@@ -140,7 +143,9 @@ def main():
         slots_all = slots
 
     if rank == 0:
-        bytes_per_slot = BYTES_PER_SLOT_DIAG + BYTES_PER_SLOT_CLUSTER + (0.0 if args.no_loop else BYTES_PER_SLOT_LOOP)
+        bytes_per_slot = BYTES_PER_SLOT_DIAG + BYTES_PER_SLOT_CLUSTER + (0.0 if (args.no_loop or args.rvb) else BYTES_PER_SLOT_LOOP)
+        if args.rvb:
+            bytes_per_slot += 8.0  # find_constants reads the op-string twice (count + fill); window traffic not counted
         alg_bytes_launch = bytes_per_slot * slots / max(1, launches)  # one launch = one sweep of rank 0's R replicas
         kernel_ms_per_launch = kernel_ms / max(1, launches)  # HIP events around the K launches on their stream
         achieved = alg_bytes_launch / (kernel_ms_per_launch * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -158,8 +163,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 op words, f64 acceptance arithmetic",
             "data": "synthetic (op-strings equilibrated on device from random spins, Philox seed %d)" % args.seed,
-            "config": {"workload": f"configs[1]: {L}x{L} periodic TFIM J=-1 Gamma=1 h=0 beta={beta}, {R} replicas/GPU, "
-                                   f"Qmc::timestep = diagonal + {'directed loop + ' if not args.no_loop else ''}cluster + free spins",
+            "config": {"workload": f"configs[{2 if args.rvb else 1}]: {L}x{L} periodic TFIM J=-1 Gamma=1 h=0 beta={beta}, {R} replicas/GPU, "
+                                   f"{'QmcIsingGraph::timestep = diagonal + RVB sweep + ' if args.rvb else 'Qmc::timestep = diagonal + ' + ('directed loop + ' if not args.no_loop else '')}cluster + free spins",
                        "replicas_per_gpu": R, "lattice": f"{L}x{L}", "beta": beta,
                        "mean_cutoff_M": mean_M, "mean_n": mean_n, "sweeps_per_s": args.steps / dt,
                        "waves_per_replica": g.launch_info()["waves_per_replica"],

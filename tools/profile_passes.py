@@ -31,6 +31,9 @@ t(lambda: g.flip_free_spins(), "free (with touch scan)")
 t(lambda: g.run(1, beta), "timestep diag+cluster+free")
 t(lambda: g.run(1, beta, flags=im.FLAG_LOOP), "timestep +loop")
 t(lambda: g.run(1, beta, flags=im.FLAG_HEATBATH), "timestep heatbath")
+if not os.environ.get("SKIP_RVB"):
+    t(lambda: g.single_rvb_sweep(), "rvb sweep (N+1)/2 attempts")
+    t(lambda: g.run(1, beta, flags=im.FLAG_RVB), "timestep with rvb")
 t(lambda: g.run(10, beta), "10 timesteps fused")
 
 tk = g.debug_phase_ticks()
