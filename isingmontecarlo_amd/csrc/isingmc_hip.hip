@@ -135,6 +135,11 @@ static int check_errors(isingmc_batch *b) {
                 b->err = buf;
                 return ISINGMC_ECAPACITY;
             }
+            if (err[r] == 8u) {
+                snprintf(buf, sizeof buf, "replica %u: more than 65534 transverse ops inside one wave's range of the cluster scan; raise waves_per_replica", r);
+                b->err = buf;
+                return ISINGMC_ECAPACITY;
+            }
             if (err[r] == 6u || err[r] == 7u || err[r] == 5u) {
                 snprintf(buf, sizeof buf, "replica %u: RVB working set exceeds the LDS scratch (code %u)", r, err[r]);
                 b->err = buf;
@@ -278,11 +283,6 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     // chunk grid for the per-chunk counters: <= SSE_MAX_CHUNKS chunks of CH slots, CH a multiple of 256
     D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
     D.nchunks = (D.cap + D.CH - 1) / D.CH;
-    // the cluster scan keeps 16-bit cut ranks per wave range: a range holds at most ceil(chunks/W)*CH slots
-    if ((size_t)((D.nchunks + W - 1) / W) * D.CH >= 65535u) {
-        b->err = "capacity per wave exceeds 65534 slots: raise waves_per_replica (16) or lower capacity";
-        return fail(ISINGMC_ENOTIMPL);
-    }
     if (cfg->lds_uf_ids_limit && ufcap > cfg->lds_uf_ids_limit) ufcap = cfg->lds_uf_ids_limit;
     D.lds_ufcap = (uint32_t)ufcap;
     b->W = W; b->K = K; b->CL = CL ? 1u : 0u;

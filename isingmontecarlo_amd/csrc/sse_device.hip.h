@@ -612,7 +612,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
 // longitudinal weight function of qmc_ising.rs:759-775.  Returns the number of clusters.
 template <int W, int K, bool CL, bool UF_GLOBAL>
 __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double prob,
-                                                 uint32_t M, int n, int ntrans, uint32_t &gr) {
+                                                 uint32_t M, int n, int ntrans, uint32_t &gr, uint32_t &err) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t N = B.N, nwords = B.nwords;
@@ -628,6 +628,16 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     if (tid == 0) { LDSW(L.o_misc, MISC_NCLUST) = 0u; LDSW(L.o_misc, MISC_ANYFROZEN) = 0u; }
     if (n == 0) { __syncthreads(); return 0u; } // cluster.rs:46-48
     SSE_STAMP_INIT;
+    { // the scan stores 16-bit cut ranks per wave range: every range must hold fewer than 65535 cuts
+        const uint32_t used = (M + B.CH - 1) / B.CH, q = (used + W - 1) / W;
+        uint32_t bad = 0;
+        for (uint32_t w2 = 0; w2 < (uint32_t)W; ++w2) {
+            uint32_t cuts = 0;
+            for (uint32_t c = min(w2 * q, used); c < min(w2 * q + q, used); ++c) cuts += LDSW(L.o_chtr, c);
+            bad |= (cuts >= 65535u);
+        }
+        if (bad) { err = 8u; return 0u; }
+    }
     const uint32_t C = (uint32_t)ntrans;            // one id per cut (transverse op)
     const uint32_t S = N + C + (uint32_t)(W - 1) * N; // + artificial range-boundary placeholders
     for (uint32_t i = tid; i < N; i += NT) uf.set(i, i);
@@ -954,10 +964,11 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
         }
         if (A.domask & SSE_DO_CLUSTER) {
             const Rng rng = make_rng(B, r, epoch);
-            if ((uint32_t)W * B.N + (uint32_t)ntrans <= B.lds_ufcap) last_out = cluster_pass<W, K, CL, false>(B, L, r, rng, A.prob, M, n, ntrans, gr);
-            else last_out = cluster_pass<W, K, CL, true>(B, L, r, rng, A.prob, M, n, ntrans, gr);
+            if ((uint32_t)W * B.N + (uint32_t)ntrans <= B.lds_ufcap) last_out = cluster_pass<W, K, CL, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+            else last_out = cluster_pass<W, K, CL, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             epoch++;
             a4 += (uint64_t)n;
+            if (err) break;
         }
         if (A.domask & SSE_DO_FREE) {
             const Rng rng = make_rng(B, r, epoch);

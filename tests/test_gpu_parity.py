@@ -226,3 +226,16 @@ def test_rvb_fused_timesteps(oracle):
     for r, rep in enumerate(reps):
         assert np.array_equal(acc[r, :7], rep.accumulators()[:7])
     assert g.verify().all()
+
+
+def test_large_lattice_64x64_runs_and_matches(oracle):
+    """configs[3] geometry (64x64): edge table in LDS, union-find in HBM, many chunks per wave."""
+    edges = lat.two_d_ferro(64)
+    R = 2
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 4096, 1 << 17, 6464, R)
+    info = g.launch_info()
+    g.run(14, 2.0)
+    oracle.batch_timesteps(reps, 14, [2.0] * R)
+    assert_same(g, reps, "64x64")
+    assert g.verify().all()
+    assert 8 * 4096 + 2000 > info["lds_uf_ids"]  # W*N + cuts exceeds the LDS union-find: HBM path exercised
