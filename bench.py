@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--equilibrate", type=int, default=80, help="untimed sweeps that prepare the synthetic input")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--no-lds-tables", action="store_true")
     ap.add_argument("--no-loop", action="store_true")
     ap.add_argument("--rvb", action="store_true", help="configs[2]: QmcIsingGraph::timestep with RVB sweeps (no directed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,10 +106,12 @@ def main():
     n_est = beta * (3 * L * L + 2.2 * L * L)
     cap = 1 << int(np.ceil(np.log2(2.0 * n_est + 4 * L * L)))
     g = im.QmcIsingGraph(edges, 1.0, 0.0, L * L, args.seed, nreplicas=R, capacity=cap,
-                         replica_offset=rank * R, device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k)
+                         replica_offset=rank * R, device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k,
+                         cfg_flags=im.CFG_NO_LDS_TABLES if args.no_lds_tables else 0)
     # data preparation: equilibrate (cutoff growth + thermalisation), untimed.  FLAG_PREP runs the identical
     # kernel under its "data preparation" symbol so that rocprofv3 --stats averages only the measured launches.
-    g.run(args.equilibrate, beta, flags=(flags & ~im.FLAG_RVB) | im.FLAG_PREP)
+    for _ in range(0, args.equilibrate, 10):  # in chunks: the LDS union-find capacity adapts between launches
+        g.run(min(10, args.equilibrate), beta, flags=(flags & ~im.FLAG_RVB) | im.FLAG_PREP)
     # one kernel launch per sweep: a "launch" in the roofline object is one sweep of all R replicas
     g.set_steps_per_launch(1)
     if args.warmup:
@@ -169,6 +172,7 @@ def main():
                        "mean_cutoff_M": mean_M, "mean_n": mean_n, "sweeps_per_s": args.steps / dt,
                        "waves_per_replica": g.launch_info()["waves_per_replica"],
                        "slots_per_lane": g.launch_info()["slots_per_lane"],
+                       "lds_bytes_per_workgroup": g.launch_info()["lds_bytes"],
                        "energy_per_site": float(energy.mean() / (L * L)),
                        "energy_per_site_sem": float(energy.std(ddof=1) / np.sqrt(R) / (L * L)) if R > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -60,7 +60,7 @@ typedef struct isingmc_config {
     uint32_t replica_offset;  /* global index of local replica 0 (replica sharding over GPUs) */
     int32_t device;           /* HIP device ordinal, -1 = current device */
     const uint8_t *init_state; /* [R][N] 0/1 or NULL = random (make_random_spin_state, classical/graph.rs:451) */
-    uint32_t waves_per_replica; /* 0 = auto (8); workgroup = this many wave64s cooperating on one replica: 1,4,8,16 */
+    uint32_t waves_per_replica; /* 0 = auto (4); workgroup = this many wave64s cooperating on one replica: 1,4,6,8,16 */
     uint32_t slots_per_lane;    /* 0 = auto (4); op-string slots each lane holds per tile: 1,2,4 */
     uint32_t flags;             /* ISINGMC_CFG_* */
     uint32_t lds_uf_ids_limit;  /* 0 = as many cluster-segment ids as fit in LDS; smaller values force the HBM

@@ -6,10 +6,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libisingmc_hip.so")
-SOURCES = ["isingmc_hip.hip", "sweep_w1.hip", "sweep_w4.hip", "sweep_w8.hip", "sweep_w16.hip"]
+SOURCES = ["isingmc_hip.hip", "sweep_w1.hip", "sweep_w4.hip", "sweep_w6.hip", "sweep_w8.hip", "sweep_w16.hip"]
 HEADERS = ["sse_device.hip.h", os.path.join("..", "..", "include", "isingmc_hip.h"),
            os.path.join("..", "..", "include", "sse_format.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+if os.environ.get("SSE_MIN_WAVES"):  # experiment: force the register budget for N waves per SIMD (W = 8 kernels)
+    FLAGS.append("-DSSE_MIN_WAVES_PER_SIMD=" + os.environ["SSE_MIN_WAVES"])
 if os.environ.get("SSE_PHASE_TIMING"):  # diagnostic build: in-kernel phase stamps (never benchmarked)
     FLAGS.append("-DSSE_PHASE_TIMING")
 

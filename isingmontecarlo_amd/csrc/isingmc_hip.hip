@@ -21,7 +21,8 @@ struct isingmc_batch {
     uint32_t acc_rows = 0;
     uint32_t rvb_updates = 0;
     uint32_t *d_acc_row = nullptr;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds_bytes_rvb = 0, lds_fixed_words_ = 0, lds_total_words = 0;
+    uint32_t max_ntrans = 0, uf_ids_limit = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -123,10 +124,29 @@ static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t 
     return (size_t)nwords * (W + 2) + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + 64 * W + ledges + ((size_t)W * N + 1) / 2;
 }
 
+// LDS footprint of the next launch.  The union-find of the cluster pass lives in LDS as 16-bit parents when all
+// ids fit; its capacity follows the largest transverse-op count seen so far (+ headroom), so that the footprint
+// stays small enough for two workgroups per CU whenever the model allows it.  Replicas that outgrow it use the HBM
+// union-find for that sweep and the host enlarges the table before the next launch.
+static void size_lds(isingmc_batch *b) {
+    DevBatch &D = b->dev;
+    const size_t ids_max = (size_t)b->W * D.N + D.cap;
+    size_t ids = (size_t)b->W * D.N + b->max_ntrans + b->max_ntrans / 16 + 384;
+    if (b->uf_ids_limit) ids = b->uf_ids_limit;
+    if (ids > 65535) ids = 65535;
+    if (ids > ids_max) ids = ids_max;
+    auto words = [&](size_t n) { return (n + 1) / 2 + (D.has_long ? 2 * ((n + 31) / 32) : 0); };
+    while (ids > 0 && b->lds_fixed_words_ + words(ids) > b->lds_total_words) ids -= (ids > 64 ? 64 : ids);
+    D.lds_ufcap = (uint32_t)ids;
+    b->lds_bytes = (4 * (b->lds_fixed_words_ + words(ids)) + 7) & ~(size_t)7;
+}
+
 static int check_errors(isingmc_batch *b) {
-    std::vector<uint32_t> err(b->dev.R);
+    std::vector<uint32_t> err(b->dev.R), ntr(b->dev.R);
     HIP_TRY(b, hipMemcpyAsync(err.data(), b->dev.err, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipMemcpyAsync(ntr.data(), b->dev.ntrans, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
+    for (uint32_t r = 0; r < b->dev.R; ++r) if (ntr[r] > b->max_ntrans) b->max_ntrans = ntr[r];
     for (uint32_t r = 0; r < b->dev.R; ++r)
         if (err[r]) {
             char buf[160];
@@ -173,7 +193,10 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     A.out_u32 = out_host ? b->d_out : nullptr;
     A.rvb_updates = b->rvb_updates;
     LaunchCfg lc{};
-    lc.W = b->W; lc.K = b->K; lc.CL = b->CL; lc.phase = (domask >> 16) & 1u; lc.lds_bytes = b->lds_bytes; lc.stream = b->stream;
+    lc.W = b->W; lc.K = b->K; lc.CL = b->CL; lc.phase = (domask >> 16) & 1u; lc.stream = b->stream;
+    size_lds(b);
+    lc.lds_bytes = ((domask & SSE_DO_RVB) && b->lds_bytes_rvb > b->lds_bytes) ? b->lds_bytes_rvb : b->lds_bytes;
+    b->dev.lds_words = (uint32_t)(lc.lds_bytes / 4);
     const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;
     uint32_t launches = 0;
     HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
@@ -184,6 +207,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         switch (b->W) {
         case 1: e = launch_sweep_w1(lc, b->dev, A); break;
         case 4: e = launch_sweep_w4(lc, b->dev, A); break;
+        case 6: e = launch_sweep_w6(lc, b->dev, A); break;
         case 8: e = launch_sweep_w8(lc, b->dev, A); break;
         case 16: e = launch_sweep_w16(lc, b->dev, A); break;
         default: b->err = "unsupported waves_per_replica"; return ISINGMC_EINVAL;
@@ -263,9 +287,11 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     int max_lds = 0;
     if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || max_lds <= 0) max_lds = 65536;
     const size_t total_words = (size_t)max_lds / 4;
-    uint32_t W = cfg->waves_per_replica ? cfg->waves_per_replica : 8;
+    // default 4 waves per replica: with 16-bit union-find parents the footprint at the headline size stays below half
+    // of the 160 KB LDS, so two workgroups share a CU and overlap each other's barriers (measured best on MI355X)
+    uint32_t W = cfg->waves_per_replica ? cfg->waves_per_replica : 4;
     uint32_t K = cfg->slots_per_lane ? cfg->slots_per_lane : 4;
-    if (W != 1 && W != 4 && W != 8 && W != 16) { b->err = "waves_per_replica must be 1, 4, 8 or 16"; return fail(ISINGMC_EINVAL); }
+    if (W != 1 && W != 4 && W != 6 && W != 8 && W != 16) { b->err = "waves_per_replica must be 1, 4, 6, 8 or 16"; return fail(ISINGMC_EINVAL); }
     if (K != 1 && K != 2 && K != 4) { b->err = "slots_per_lane must be 1, 2 or 4"; return fail(ISINGMC_EINVAL); }
     // compact edge table staged in LDS when it is small enough (a|c<<15|pref<<30 needs N <= 32768)
     // uniform |J| lets the kernels keep the two-site weight in a scalar register
@@ -273,28 +299,24 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     for (uint32_t e = 1; e < D.E; ++e) if (tab[e].w != tab[0].w) { D.uniformJ = 0u; break; }
     const bool CL = D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
     const uint32_t ledges = CL ? D.E : 0u;
-    while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : W >> 1;
+    while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : (W == 6 ? 4 : W >> 1);
     const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges);
     if (fixed + 64 > total_words) { b->err = "model too large: per-variable scan tables do not fit in LDS"; return fail(ISINGMC_ENOTIMPL); }
-    const size_t remaining = total_words - fixed;
-    size_t ufcap = (remaining - 2) * 32 / 34;
     const size_t ids_max = (size_t)W * D.N + D.cap;
-    if (ufcap > ids_max) ufcap = ids_max;
     // chunk grid for the per-chunk counters: <= SSE_MAX_CHUNKS chunks of CH slots, CH a multiple of 256
     D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
     D.nchunks = (D.cap + D.CH - 1) / D.CH;
-    if (cfg->lds_uf_ids_limit && ufcap > cfg->lds_uf_ids_limit) ufcap = cfg->lds_uf_ids_limit;
-    D.lds_ufcap = (uint32_t)ufcap;
     b->W = W; b->K = K; b->CL = CL ? 1u : 0u;
-    b->lds_bytes = 4 * (fixed + ufcap + 2 * ((ufcap + 31) / 32));
-    { // the RVB pass reuses everything from the scan tables on: make sure its scratch and constant-op table fit
+    b->lds_fixed_words_ = fixed; b->lds_total_words = total_words; b->uf_ids_limit = cfg->lds_uf_ids_limit;
+    { // the RVB pass reuses everything from the scan tables on: launches that run it get enough LDS for its scratch
+      // and constant-op table (other launches keep the smaller footprint, which decides workgroups per CU)
         const size_t o_cur = fixed - ((size_t)W * D.N + 1) / 2;
         const size_t want = 4 * (o_cur + 2 + rvb_fixed_words(D.N, D.E) + (size_t)D.cap);
-        const size_t capped = want < (size_t)max_lds ? want : (size_t)max_lds;
-        if (capped > b->lds_bytes) b->lds_bytes = capped & ~(size_t)7;
+        b->lds_bytes_rvb = (want < (size_t)max_lds ? want : (size_t)max_lds) & ~(size_t)7;
     }
-    D.lds_words = (uint32_t)(b->lds_bytes / 4);
+    size_lds(b);
     D.gamma = cfg->transverse; D.wh = 2.0 * std::fabs(cfg->longitudinal); D.hpos = cfg->longitudinal > 0.0 ? 1u : 0u;
+    D.has_long = has_long ? 1u : 0u;
 
     int rc;
     if ((rc = dalloc(b, &D.ops, (size_t)D.R * D.cap))) return fail(rc);
@@ -587,6 +609,7 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
     if (nwords > cur) HIP_TRY(b, hipMemcpy(b->dev.cutoff + r, &nwords, 4, hipMemcpyHostToDevice));
     HIP_TRY(b, hipMemcpy(b->dev.n + r, &n, 4, hipMemcpyHostToDevice));
     HIP_TRY(b, hipMemcpy(b->dev.ntrans + r, &ntr, 4, hipMemcpyHostToDevice));
+    if (ntr > b->max_ntrans) b->max_ntrans = ntr;
     HIP_TRY(b, hipMemcpy(b->dev.chunks + (size_t)r * 2 * SSE_MAX_CHUNKS, chunks.data(), sizeof(uint32_t) * chunks.size(), hipMemcpyHostToDevice));
     return ISINGMC_OK;
 }

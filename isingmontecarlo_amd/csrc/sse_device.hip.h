@@ -48,7 +48,7 @@ struct DevBatch {
     const double *cumw;   // [Nb] heat-bath cumulative weights
     double wtot;
     double wJ, gamma, wh; // uniform 2|J| (if uniformJ), Gamma, 2|h|
-    uint32_t uniformJ, hpos;
+    uint32_t uniformJ, hpos, has_long;
     uint32_t *chunks;     // [R][2*SSE_MAX_CHUNKS]: per chunk of CH slots: occupied count, transverse-op count
     uint32_t CH, nchunks; // chunk size (multiple of 256 slots) and number of chunks covering cap
     uint32_t *uf_scratch; // [R][W*N+cap (+bit arrays)] union-find fallback in HBM
@@ -162,8 +162,8 @@ struct Lds {           // word offsets into lds_raw
     uint32_t o_cur;    // [W][N] u16    per wave: rank+1 (within the wave's range) of the latest cut on each variable
     uint32_t o_frozen; // [ufwords]     bit per id: segment holds a longitudinal op
     uint32_t o_froot;  // [ufwords]     bit per id: root is frozen
-    uint32_t o_parent; // [ufcap]
-    __device__ __forceinline__ void carve(uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges) {
+    uint32_t o_parent; // [ufcap] u16 (the LDS union-find is only used when every id fits 16 bits)
+    __device__ __forceinline__ void carve(uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges, uint32_t has_long) {
         uint32_t base = 0;
         o_state = base; base += nwords;
         o_scopy = base; base += W * nwords;
@@ -176,8 +176,8 @@ struct Lds {           // word offsets into lds_raw
         o_cutlane = base; base += W * 64;
         o_edges = base; base += ledges;
         o_cur = base; base += (W * N + 1) / 2;
-        o_frozen = base; base += (ufcap + 31) / 32;
-        o_froot = base; base += (ufcap + 31) / 32;
+        o_frozen = base; base += has_long ? (ufcap + 31) / 32 : 0u;
+        o_froot = base; base += has_long ? (ufcap + 31) / 32 : 0u;
         o_parent = base;
     }
 };
@@ -457,10 +457,24 @@ template <bool G>
 struct UFA {
     uint32_t *gparent, *gfrozen, *gfroot; // HBM arrays (G)
     uint32_t o_parent, o_frozen, o_froot; // lds_raw offsets (!G)
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { if constexpr (G) return gparent[i]; else return LDSW(o_parent, i); }
-    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { if constexpr (G) gparent[i] = v; else LDSW(o_parent, i) = v; }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { if constexpr (G) return gparent[i]; else return (uint32_t)LDSH(o_parent, i); }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { if constexpr (G) gparent[i] = v; else LDSH(o_parent, i) = (uint16_t)v; }
     __device__ __forceinline__ uint32_t cas(uint32_t i, uint32_t cmp, uint32_t v) const {
-        if constexpr (G) return atomicCAS(&gparent[i], cmp, v); else return atomicCAS(&LDSW(o_parent, i), cmp, v);
+        if constexpr (G) return atomicCAS(&gparent[i], cmp, v);
+        else {
+            // 16-bit compare-and-swap through a 32-bit CAS on the containing word; a concurrent 16-bit store to
+            // the other half only makes the CAS fail and retry with the value it returned
+            const uint32_t widx = i >> 1, sh = (i & 1u) * 16u;
+            uint32_t old = __hip_atomic_load(&LDSW(o_parent, widx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+                const uint32_t cur = (old >> sh) & 0xFFFFu;
+                if (cur != cmp) return cur;
+                const uint32_t neww = (old & ~(0xFFFFu << sh)) | (v << sh);
+                const uint32_t prev = atomicCAS(&LDSW(o_parent, widx), old, neww);
+                if (prev == old) return cmp;
+                old = prev;
+            }
+        }
     }
     __device__ __forceinline__ void frozen_or(uint32_t w, uint32_t bits) const { if constexpr (G) atomicOr(&gfrozen[w], bits); else atomicOr(&LDSW(o_frozen, w), bits); }
     __device__ __forceinline__ void froot_or(uint32_t w, uint32_t bits) const { if constexpr (G) atomicOr(&gfroot[w], bits); else atomicOr(&LDSW(o_froot, w), bits); }
@@ -642,7 +656,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     const uint32_t S = N + C + (uint32_t)(W - 1) * N; // + artificial range-boundary placeholders
     for (uint32_t i = tid; i < N; i += NT) uf.set(i, i);
     for (uint32_t i = tid; i < (uint32_t)(W - 1) * N; i += NT) uf.set(N + C + i, N + C + i);
-    for (uint32_t i = tid; i < (S + 31) / 32; i += NT) uf.bits_clear(i);
+    if (B.has_long) for (uint32_t i = tid; i < (S + 31) / 32; i += NT) uf.bits_clear(i);
     __syncthreads();
     // ---- build: label legs with segment ids, union through non-boundary ops ----
     SSE_STAMP(0);
@@ -664,7 +678,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     for (uint32_t i = tid; i < S; i += NT) {
         const uint32_t root = uf_find(uf, i);
         uf.set(i, root);
-        if ((uf.frozen_get(i >> 5) >> (i & 31)) & 1u) { uf.froot_or(root >> 5, 1u << (root & 31)); LDSW(L.o_misc, MISC_ANYFROZEN) = 1u; }
+        if (B.has_long && ((uf.frozen_get(i >> 5) >> (i & 31)) & 1u)) { uf.froot_or(root >> 5, 1u << (root & 31)); LDSW(L.o_misc, MISC_ANYFROZEN) = 1u; }
     }
     __syncthreads();
     SSE_STAMP(3);
@@ -684,7 +698,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
         } else {
             if (root == i && touched && i < N + C) myclusters++;
             const uint4 o = rng.draw(SSE_TAG_CLUSTER, root);
-            const uint32_t isfrozen = (uf.froot_get(root >> 5) >> (root & 31)) & 1u;
+            const uint32_t isfrozen = B.has_long ? (uf.froot_get(root >> 5) >> (root & 31)) & 1u : 0u;
             f = (!isfrozen && u01(o.x) < prob) ? 1u : 0u;
         }
         uf.set(i, f);
@@ -918,11 +932,14 @@ namespace sse {
 // QmcStepper::timesteps_measure_with_self (qmc_traits/qmc_stepper.rs:133-162).
 // PHASE only tags the symbol (0 = measured path, 1 = data preparation) so that profilers can tell the
 // two apart; the code is identical.
+#ifndef SSE_MIN_WAVES_PER_SIMD
+#define SSE_MIN_WAVES_PER_SIMD 1
+#endif
 template <int W, int K, bool CL, int PHASE>
-__global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) {
+__global__ __launch_bounds__(W * 64, (W == 8 ? SSE_MIN_WAVES_PER_SIMD : (W == 6 ? 3 : 1))) void sweep_kernel(DevBatch B, SweepArgs A) {
     constexpr int NT = W * 64;
     Lds<W> L;
-    L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u);
+    L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u, B.has_long);
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
     for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_state, i) = B.state[(size_t)r * B.nwords + i];
@@ -964,7 +981,8 @@ __global__ __launch_bounds__(W * 64) void sweep_kernel(DevBatch B, SweepArgs A) 
         }
         if (A.domask & SSE_DO_CLUSTER) {
             const Rng rng = make_rng(B, r, epoch);
-            if ((uint32_t)W * B.N + (uint32_t)ntrans <= B.lds_ufcap) last_out = cluster_pass<W, K, CL, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+            const uint32_t S_ids = (uint32_t)W * B.N + (uint32_t)ntrans;
+            if (S_ids <= B.lds_ufcap && S_ids <= 65535u) last_out = cluster_pass<W, K, CL, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             else last_out = cluster_pass<W, K, CL, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             epoch++;
             a4 += (uint64_t)n;
@@ -1008,6 +1026,7 @@ struct LaunchCfg {
 // one translation unit per W (sweep_w*.hip) defines these
 hipError_t launch_sweep_w1(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_w4(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
+hipError_t launch_sweep_w6(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_w8(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_w16(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 

@@ -42,7 +42,7 @@ CASES = [
 ]
 
 
-GEOMS = [(1, 1, 0), (1, 4, 0), (4, 2, 0), (4, 4, 1), (8, 1, 0), (8, 4, 0), (8, 4, 1), (16, 4, 0), (16, 2, 1)]
+GEOMS = [(1, 1, 0), (1, 4, 0), (4, 2, 0), (4, 4, 1), (6, 2, 0), (6, 4, 1), (8, 1, 0), (8, 4, 0), (8, 4, 1), (16, 4, 0), (16, 2, 1)]
 
 
 @pytest.mark.parametrize("waves", [1, 4, 8])
