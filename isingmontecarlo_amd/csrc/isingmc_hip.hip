@@ -337,6 +337,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         D.acc_row = b->d_acc_row;
     }
     if ((rc = dalloc(b, &D.chunks, (size_t)D.R * 2 * SSE_MAX_CHUNKS))) return fail(rc);
+    if ((rc = dalloc(b, &D.segs, (size_t)D.R * D.cap, false))) return fail(rc);
     if ((rc = dalloc(b, &D.dbg, (size_t)D.R * 16))) return fail(rc);
     BondRec *dbonds = nullptr; double *dcum = nullptr;
     if ((rc = dalloc(b, &dbonds, D.Nb, false))) return fail(rc);

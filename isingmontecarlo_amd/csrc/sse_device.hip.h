@@ -49,6 +49,9 @@ struct DevBatch {
     double wtot;
     double wJ, gamma, wh; // uniform 2|J| (if uniformJ), Gamma, 2|h|
     uint32_t uniformJ, hpos, has_long;
+    uint32_t *segs;       // [R][cap] segment ids of every slot's two legs (lo | hi << 16), written by the cluster build
+                          // and read by the apply pass of the LDS union-find path (spends spare HBM bandwidth to
+                          // avoid recomputing the ordered scan)
     uint32_t *chunks;     // [R][2*SSE_MAX_CHUNKS]: per chunk of CH slots: occupied count, transverse-op count
     uint32_t CH, nchunks; // chunk size (multiple of 256 slots) and number of chunks covering cap
     uint32_t *uf_scratch; // [R][W*N+cap (+bit arrays)] union-find fallback in HBM
@@ -610,6 +613,10 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                 }
                 if (two) uf_union(uf, seg_a, seg_c);
                 if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
+                if constexpr (!G) { // ids fit 16 bits on this path: remember them for the apply pass
+                    const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
+                    B.segs[(size_t)r * B.cap + p0 + j * 64 + lane] = seg_a | (hi << 16);
+                }
             } else {
                 const uint32_t fa = uf.get(seg_a), fc = uf.get(seg_c), fo = uf.get(iscut ? id_own : seg_a);
                 const uint32_t f2 = two ? (fc << 1) : 0u;
@@ -617,6 +624,42 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                 const uint32_t neww = (wd & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
                 if (nonempty & (neww != wd)) ops[p0 + j * 64 + lane] = neww;
             }
+        }
+    }
+    __syncthreads();
+}
+
+// Apply pass of the LDS union-find path (cluster.rs:139-167): every slot's segment ids were stored by the build
+// scan, flip bits sit in the (flattened) parent table, so the slots can be rewritten in any order: plain strided
+// streaming, no ordered scan.  Input bits flip with the incoming segment, output bits with the outgoing one.
+template <int W, int K, bool CL>
+__device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<false> &uf) {
+    constexpr int NT = W * 64;
+    const int tid = threadIdx.x;
+    uint32_t *ops = B.ops + (size_t)r * B.cap;
+    const uint32_t *segs = B.segs + (size_t)r * B.cap;
+    for (uint32_t p0 = 0; p0 < M; p0 += (uint32_t)(K * NT)) {
+        uint32_t wd[K], sg[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t p = p0 + (uint32_t)(j * NT + tid);
+            wd[j] = p < M ? ops[p] : 0u;
+            sg[j] = p < M ? segs[p] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t w = wd[j];
+            const bool nonempty = w != 0u;
+            const uint32_t fa = uf.get(sg[j] & 0xFFFFu), fb = uf.get(sg[j] >> 16);
+            bool two;
+            if constexpr (CL) two = nonempty & (sse_op_bond(w) < B.E);
+            else two = nonempty & (decode_bond<CL, W>(B, L, nonempty ? sse_op_bond(w) : 0u).c != SSE_NO_VAR);
+            // two-site: both legs of variable a carry fa, both legs of variable c carry fb;
+            // single-site: the input leg carries fa (incoming segment), the output leg fb (outgoing segment)
+            const uint32_t in = sse_op_in(w) ^ (two ? (fa | (fb << 1)) : fa);
+            const uint32_t out = sse_op_out(w) ^ (two ? (fa | (fb << 1)) : fb);
+            const uint32_t neww = (w & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
+            if (nonempty & (neww != w)) ops[p0 + (uint32_t)(j * NT + tid)] = neww;
         }
     }
     __syncthreads();
@@ -711,7 +754,8 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     __syncthreads();
     SSE_STAMP(4);
     // ---- apply (cluster.rs:139-167) ----
-    cluster_scan<W, K, CL, true, UF_GLOBAL>(B, L, r, M, uf, C);
+    if constexpr (UF_GLOBAL) cluster_scan<W, K, CL, true, UF_GLOBAL>(B, L, r, M, uf, C);
+    else cluster_apply_cached<W, K, CL>(B, L, r, M, uf);
     SSE_STAMP(5);
     // p=0 state follows the placeholder segment of each touched variable
     for (uint32_t i = tid; i < nwords; i += NT) {
