@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--rvb", action="store_true", help="configs[2]: QmcIsingGraph::timestep with RVB sweeps (no directed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run (profiles/README.md)")
     args = ap.parse_args()
 
     import numpy as np
@@ -176,7 +178,7 @@ def main():
                        "energy_per_site": float(energy.mean() / (L * L)),
                        "energy_per_site_sem": float(energy.std(ddof=1) / np.sqrt(R) / (L * L)) if R > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic_bytes,
                          "kernel": "sse::sweep_kernel<W,K,CL,0>", "kernel_ms_per_launch": kernel_ms_per_launch, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "bytes_per_slot": bytes_per_slot},
         }
