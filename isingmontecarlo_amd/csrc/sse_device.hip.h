@@ -275,7 +275,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         uint32_t bsel[K], sub[K], evA[K], xb[K];
         double num[K], u[K];
         int cand[K]; // +1 insertion candidate, -1 removal candidate, 0 none
-        bool tr[K];
+        uint64_t trm[K]; // lanes whose (candidate or present) op is a transverse-field op
         uint4 rnd = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -314,7 +314,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             const uint32_t vc = two ? d.c : va;
             bsel[j] = b;
             evA[j] = va;
-            tr[j] = bd_kind(d) == SSE_BOND_TRANSVERSE;
+            trm[j] = __ballot(bd_kind(d) == SSE_BOND_TRANSVERSE);
             // spin reads (unconditional, safe indices): own copy xor earlier off-diagonal events of this
             // sub-round.  Ising bonds: only single-site ops can be off-diagonal (bit 0 of in^out).
             uint32_t sa = (LDSW(o_mycopy, va >> 5) >> (va & 31)) & 1u;
@@ -353,8 +353,8 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         for (int j = 0; j < K; ++j) { npref[j] = n_start; dec_prev[j] = 2; dec[j] = 0; }
         int tot_all = 0;
         bool first = true;
+        uint64_t im[K], rm[K];
         for (;;) {
-            uint64_t im[K], rm[K];
             bool changed = false;
             int wtot = 0;
 #pragma unroll
@@ -424,20 +424,21 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         if (threadIdx.x == 0) B.dbg[(size_t)r * 16 + 12] += 1; // tiles
 #endif
         // ---- commit ----
+        int dn = 0, dtr = 0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if (dec[j] != 0) {
                 const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
                 ops[p] = dec[j] > 0 ? sse_op_make(bsel[j], sub[j], sub[j]) : 0u;
             }
-            const int dtr = popc64(__ballot(dec[j] > 0 && tr[j])) - popc64(__ballot(dec[j] < 0 && tr[j]));
-            const int dn = popc64(__ballot(dec[j] > 0)) - popc64(__ballot(dec[j] < 0));
-            ntrans += dtr;
-            if (lane == 0 && (dtr | dn)) { // a sub-round's 64 slots lie inside one chunk (CH is a multiple of 256)
-                const uint32_t ch = slot_of<W, K>(tile, wave, j, 0) / B.CH;
-                if (dn) atomicAdd(&LDSW(L.o_chn, ch), (uint32_t)dn);
-                if (dtr) atomicAdd(&LDSW(L.o_chtr, ch), (uint32_t)dtr);
-            }
+            dn += popc64(im[j]) - popc64(rm[j]);
+            dtr += popc64(im[j] & trm[j]) - popc64(rm[j] & trm[j]);
+        }
+        ntrans += dtr;
+        if (lane == 0 && (dtr | dn)) { // a wave's 64*K slots of a tile lie inside one chunk (CH is a multiple of 256 >= 64*K)
+            const uint32_t ch = slot_of<W, K>(tile, wave, 0, 0) / B.CH;
+            if (dn) atomicAdd(&LDSW(L.o_chn, ch), (uint32_t)dn);
+            if (dtr) atomicAdd(&LDSW(L.o_chtr, ch), (uint32_t)dtr);
         }
         n_start += tot_all;
     }
