@@ -642,6 +642,7 @@ int isingmc_set_stream(isingmc_batch *b, void *hip_stream) {
 }
 int isingmc_debug_phase_ticks(isingmc_batch *b, uint64_t *out /*[R][16]*/, int reset) {
     if (!b || !out) return ISINGMC_EINVAL;
+    if (reset >= 16) { b->dev.dbg_flags = (uint32_t)reset >> 4; reset &= 1; } // diagnostic builds: experiment flags
     HIP_TRY(b, hipSetDevice(b->device));
     HIP_TRY(b, hipMemcpy(out, b->dev.dbg, sizeof(uint64_t) * 16 * b->dev.R, hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(b, hipMemset(b->dev.dbg, 0, sizeof(uint64_t) * 16 * b->dev.R));

@@ -59,6 +59,7 @@ struct DevBatch {
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
     uint32_t lds_words;   // dynamic LDS words available to the workgroup
     const uint32_t *adj_start, *adj; // [N+1], [2E] bonds_for_var (make_classical_bonds, qmc_ising.rs:421-432)
+    uint32_t dbg_flags;   // diagnostic builds only
     unsigned long long *dbg; // [R][16] phase durations in 10-ns ticks (diagnostic builds only, -DSSE_PHASE_TIMING)
 };
 
@@ -501,6 +502,14 @@ __device__ __forceinline__ uint32_t uf_find(const UFA<G> &uf, uint32_t x) {
     }
     return x;
 }
+// Read-only find for the flatten phase: there the owner of id i overwrites parent[i] with the exact root, and a
+// path-halving store from another thread's walk could land after it and put a non-root ancestor back.
+template <bool G>
+__device__ __forceinline__ uint32_t uf_find_ro(const UFA<G> &uf, uint32_t x) {
+    uint32_t p = uf.get(x);
+    while (p != x) { x = p; p = uf.get(x); }
+    return x;
+}
 template <bool G>
 __device__ __forceinline__ void uf_union(const UFA<G> &uf, uint32_t a, uint32_t b) {
     for (;;) {
@@ -612,7 +621,11 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                     atomicOr(&LDSW(L.o_touch, va >> 5), 1u << (va & 31));
                     atomicOr(&LDSW(L.o_touch, vc >> 5), 1u << (vc & 31));
                 }
+#ifdef SSE_PHASE_TIMING
+                if (two && !(B.dbg_flags & 1u)) uf_union(uf, seg_a, seg_c); // diagnostic builds: bit 0 = time the scan without unions
+#else
                 if (two) uf_union(uf, seg_a, seg_c);
+#endif
                 if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
                 if constexpr (!G) { // ids fit 16 bits on this path: remember them for the apply pass
                     const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
@@ -720,7 +733,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     SSE_STAMP(2);
     // ---- flatten: parent[i] := exact root (no union runs any more), frozen marks move to roots ----
     for (uint32_t i = tid; i < S; i += NT) {
-        const uint32_t root = uf_find(uf, i);
+        const uint32_t root = uf_find_ro(uf, i); // no halving stores here: only exact roots may be written
         uf.set(i, root);
         if (B.has_long && ((uf.frozen_get(i >> 5) >> (i & 31)) & 1u)) { uf.froot_or(root >> 5, 1u << (root & 31)); LDSW(L.o_misc, MISC_ANYFROZEN) = 1u; }
     }

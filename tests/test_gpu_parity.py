@@ -125,6 +125,18 @@ def test_medium_lattice_many_replicas(oracle, waves, k, cfgf):
     assert g.verify().all()
 
 
+def test_many_replicas_stress(oracle):
+    # wide batch at the bench geometry: every replica runs the concurrent union-find / flatten / coin phases with
+    # its own interleaving, so an ordering bug between workgroup threads shows up as a parity break somewhere
+    edges = lat.two_d_ferro(32)
+    R = 256
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 1024, 1 << 16, 77, R)
+    g.run(12, 8.0)
+    oracle.batch_timesteps(reps, 12, [8.0] * R)
+    assert_same(g, reps, "32x32 x256")
+    assert g.verify().all()
+
+
 @pytest.mark.parametrize("waves,k", [(8, 4), (4, 1), (16, 4)])
 def test_union_find_global_fallback(oracle, waves, k):
     # cap the LDS union-find so that N + (transverse ops) exceeds it: the HBM union-find path must agree

@@ -46,3 +46,12 @@ if tk.any():
     g.single_diagonal_step(beta)
     raw = g.debug_phase_ticks().astype(float).mean(axis=0)
     print("diag phases (us per replica): compute %.1f rounds %.1f commit+loop %.1f ; tiles %.0f rounds %.0f" % (raw[8] * 10e-3, raw[9] * 10e-3, raw[11] * 10e-3, raw[12], raw[13]))
+
+    # diagnostic experiment: cluster build scan without unions (configuration is NOT advanced afterwards)
+    import ctypes as _C
+    out = np.zeros((g.nreplicas, 16), dtype=np.uint64)
+    g._lib.isingmc_debug_phase_ticks(g._h, out.ctypes.data_as(_C.POINTER(_C.c_uint64)), 16 + 1)
+    g.single_cluster_step(flip_free=False)
+    g._lib.isingmc_debug_phase_ticks(g._h, out.ctypes.data_as(_C.POINTER(_C.c_uint64)), 0)
+    tk = out.astype(float).mean(axis=0) * 10e-3
+    print("cluster phases WITHOUT unions (us): build %.1f apply %.1f" % (tk[1], tk[5]))
