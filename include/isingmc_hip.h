@@ -42,6 +42,8 @@ extern "C" {
 
 /* isingmc_config.flags */
 #define ISINGMC_CFG_NO_LDS_TABLES 1u /* keep the bond table in HBM even when it would fit in LDS (testing) */
+#define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
+                                        followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 
 typedef struct isingmc_batch isingmc_batch;
 
@@ -144,13 +146,16 @@ int isingmc_set_stream(isingmc_batch *b, void *hip_stream);
 int isingmc_synchronize(isingmc_batch *b);
 /* HIP-event timing of the most recent isingmc_timesteps launch(es): total ms and number of kernel launches */
 int isingmc_last_kernel_ms(isingmc_batch *b, float *ms, uint32_t *launches);
+/* the same run split by kernel: ms[0]/launches[0] = diagonal-pass launches, ms[1]/launches[1] = all other launches */
+int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]);
 /* diagnostic builds (-DSSE_PHASE_TIMING) only: per-replica phase durations in 10-ns ticks, out[R][16]; zero otherwise */
 int isingmc_debug_phase_ticks(isingmc_batch *b, uint64_t *out, int reset);
 /* number of sweeps fused into one kernel launch by isingmc_timesteps (0 = all t steps in one launch) */
 int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
 /* build/launch configuration actually in use: out[0]=waves per replica, out[1]=dynamic LDS bytes,
  * out[2]=union-find ids that fit in LDS, out[3]=state words per replica, out[4]=slots per lane,
- * out[5]=1 if the edge table is staged in LDS, out[6..7] reserved */
+ * out[5]=1 if the edge table is staged in LDS, out[6]=1 if timesteps are issued as two launches (diagonal, rest),
+ * out[7]=dynamic LDS bytes of the diagonal-pass launch */
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]);
 
 #ifdef __cplusplus

@@ -13,11 +13,12 @@ import numpy as np
 from . import _build
 
 __all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
-           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES"]
+           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH"]
 
 FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
 FLAG_PREP = 0x10000
 CFG_NO_LDS_TABLES = 1
+CFG_FUSED_LAUNCH = 2  # whole timesteps in one kernel launch (default: diagonal launch + off-diagonal launch)
 ALL = 0xFFFFFFFF
 
 _ERRNAMES = {-1: "EINVAL", -2: "ENODEVICE", -3: "ECAPACITY", -4: "EINTEGRITY", -5: "ENOTIMPL"}
@@ -74,6 +75,7 @@ SYMBOLS = {
     "isingmc_debug_phase_ticks": (C.c_int, [_vp, _P(_u64), C.c_int]),
     "isingmc_synchronize": (C.c_int, [_vp]),
     "isingmc_last_kernel_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
+    "isingmc_last_pass_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
     "isingmc_get_launch_info": (C.c_int, [_vp, _P(_u32)]),
 }
 
@@ -329,11 +331,18 @@ class QmcIsingGraph:
         self._check(self._lib.isingmc_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_pass_ms(self):
+        """(ms, launches) of the last run split by kernel: index 0 = diagonal-pass launches, 1 = all other launches."""
+        ms, n = (C.c_float * 2)(), (C.c_uint32 * 2)()
+        self._check(self._lib.isingmc_last_pass_ms(self._h, ms, n))
+        return (ms[0], ms[1]), (n[0], n[1])
+
     def launch_info(self):
         out = (C.c_uint32 * 8)()
         self._check(self._lib.isingmc_get_launch_info(self._h, out))
         return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3],
-                    slots_per_lane=out[4], lds_edge_table=bool(out[5]))
+                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6]),
+                    lds_bytes_diagonal=out[7])
 
     def debug_phase_ticks(self, reset=True):
         out = np.zeros((self.nreplicas, 16), dtype=np.uint64)

@@ -28,6 +28,10 @@ struct isingmc_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     uint32_t last_launches = 0;
+    bool fused_launch = false;          // ISINGMC_CFG_FUSED_LAUNCH: whole timesteps in one kernel (no diagonal-only launches)
+    std::vector<hipEvent_t> evpool;     // per-launch events of the split path (bounded, see run())
+    float pass_ms[2] = {0.f, 0.f};      // [0] diagonal-only launches, [1] all other launches of the last run
+    uint32_t pass_launches[2] = {0, 0};
     double offset = 0.0;
     std::vector<BondRec> bonds_host;
     double *d_beta = nullptr;
@@ -197,28 +201,79 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     size_lds(b);
     lc.lds_bytes = ((domask & SSE_DO_RVB) && b->lds_bytes_rvb > b->lds_bytes) ? b->lds_bytes_rvb : b->lds_bytes;
     b->dev.lds_words = (uint32_t)(lc.lds_bytes / 4);
-    const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;
-    uint32_t launches = 0;
-    HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
-    for (uint64_t done = 0; done < nsteps; done += per) {
-        A.step0 = done;
-        A.nsteps = (nsteps - done < per) ? nsteps - done : per;
-        hipError_t e;
+    auto launch = [&](const LaunchCfg &c, const SweepArgs &a) -> hipError_t {
         switch (b->W) {
-        case 1: e = launch_sweep_w1(lc, b->dev, A); break;
-        case 4: e = launch_sweep_w4(lc, b->dev, A); break;
-        case 6: e = launch_sweep_w6(lc, b->dev, A); break;
-        case 8: e = launch_sweep_w8(lc, b->dev, A); break;
-        case 16: e = launch_sweep_w16(lc, b->dev, A); break;
-        default: b->err = "unsupported waves_per_replica"; return ISINGMC_EINVAL;
+        case 1: return launch_sweep_w1(c, b->dev, a);
+        case 4: return launch_sweep_w4(c, b->dev, a);
+        case 6: return launch_sweep_w6(c, b->dev, a);
+        case 8: return launch_sweep_w8(c, b->dev, a);
+        case 16: return launch_sweep_w16(c, b->dev, a);
+        default: return hipErrorInvalidValue;
         }
-        if (e != hipSuccess) { b->err = std::string("sweep launch: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; }
-        launches++;
+    };
+    auto fail_launch = [&](hipError_t e) { b->err = std::string("sweep launch: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; };
+    uint32_t launches = 0;
+    b->pass_ms[0] = b->pass_ms[1] = 0.f;
+    b->pass_launches[0] = b->pass_launches[1] = 0;
+    const uint32_t diag_bits = SSE_DO_DIAG | SSE_DO_HEATBATH | SSE_DO_GROW;
+    const bool split = !b->fused_launch && (A.domask & SSE_DO_DIAG);
+    size_t timed_steps = 0; // split path: steps whose launches carry events
+    HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
+    if (!split) {
+        const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;
+        for (uint64_t done = 0; done < nsteps; done += per) {
+            A.step0 = done;
+            A.nsteps = (nsteps - done < per) ? nsteps - done : per;
+            const hipError_t e = launch(lc, A);
+            if (e != hipSuccess) return fail_launch(e);
+            launches++;
+        }
+        b->pass_launches[1] = launches;
+    } else {
+        // Two launches per timestep: the diagonal pass as its own kernel (twice the occupancy: it needs neither the
+        // union-find LDS nor the registers of the cluster scan), then everything else.  Same Philox epochs, same
+        // results as the fused launch; n / cutoff / chunk counters go through HBM in between (a few KB per replica).
+        LaunchCfg ld = lc;
+        ld.passes = SSE_PASSES_DIAG;
+        ld.lds_bytes = (4 * b->lds_fixed_words_ + 7) & ~(size_t)7;
+        const uint32_t rest = A.domask & ~diag_bits;
+        constexpr size_t MAX_TIMED = 256;
+        const size_t want_ev = 3 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
+        while (b->evpool.size() < want_ev) { hipEvent_t ev; HIP_TRY(b, hipEventCreate(&ev)); b->evpool.push_back(ev); }
+        for (uint64_t done = 0; done < nsteps; ++done) {
+            const bool timed = done < MAX_TIMED;
+            SweepArgs a1 = A;
+            a1.domask = A.domask & diag_bits; a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
+            if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done], b->stream));
+            hipError_t e = launch(ld, a1);
+            if (e != hipSuccess) return fail_launch(e);
+            launches++; b->pass_launches[0]++;
+            if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done + 1], b->stream));
+            const bool sample = freq && (done + 1) % freq == 0;
+            if (rest || sample) {
+                SweepArgs a2 = A;
+                a2.domask = rest; a2.nsteps = 1; a2.step0 = done;
+                e = launch(lc, a2);
+                if (e != hipSuccess) return fail_launch(e);
+                launches++; b->pass_launches[1]++;
+            }
+            if (timed) { HIP_TRY(b, hipEventRecord(b->evpool[3 * done + 2], b->stream)); timed_steps++; }
+        }
     }
     HIP_TRY(b, hipEventRecord(b->ev1, b->stream));
     int rc = check_errors(b);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) { b->last_ms = ms; b->last_launches = launches; }
+    if (!split) b->pass_ms[1] = b->last_ms;
+    for (size_t i = 0; i < timed_steps; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, b->evpool[3 * i], b->evpool[3 * i + 1]) == hipSuccess) b->pass_ms[0] += t;
+        if (hipEventElapsedTime(&t, b->evpool[3 * i + 1], b->evpool[3 * i + 2]) == hipSuccess) b->pass_ms[1] += t;
+    }
+    if (split && timed_steps && timed_steps < nsteps) { // scale the sampled steps up to the whole run
+        const float f = (float)nsteps / (float)timed_steps;
+        b->pass_ms[0] *= f; b->pass_ms[1] *= f;
+    }
     if (rc) return rc;
     if (out_host) HIP_TRY(b, hipMemcpy(out_host, b->d_out, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost));
     return ISINGMC_OK;
@@ -297,6 +352,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     // uniform |J| lets the kernels keep the two-site weight in a scalar register
     D.uniformJ = 1u; D.wJ = tab[0].w;
     for (uint32_t e = 1; e < D.E; ++e) if (tab[e].w != tab[0].w) { D.uniformJ = 0u; break; }
+    b->fused_launch = (cfg->flags & ISINGMC_CFG_FUSED_LAUNCH) != 0;
     const bool CL = D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
     const uint32_t ledges = CL ? D.E : 0u;
     while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : (W == 6 ? 4 : W >> 1);
@@ -401,6 +457,7 @@ void isingmc_destroy(isingmc_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     for (void *p : b->allocs) (void)hipFree(p);
+    for (hipEvent_t ev : b->evpool) (void)hipEventDestroy(ev);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     delete b;
@@ -665,10 +722,16 @@ int isingmc_last_kernel_ms(isingmc_batch *b, float *ms, uint32_t *launches) {
     if (launches) *launches = b->last_launches;
     return ISINGMC_OK;
 }
+int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
+    if (!b) return ISINGMC_EINVAL;
+    if (ms) { ms[0] = b->pass_ms[0]; ms[1] = b->pass_ms[1]; }
+    if (launches) { launches[0] = b->pass_launches[0]; launches[1] = b->pass_launches[1]; }
+    return ISINGMC_OK;
+}
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->CL;
+    out[4] = b->K; out[5] = b->CL; out[6] = b->fused_launch ? 0u : 1u; out[7] = (uint32_t)((4 * b->lds_fixed_words_ + 7) & ~(size_t)7);
     return ISINGMC_OK;
 }
 

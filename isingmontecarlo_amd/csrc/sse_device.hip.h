@@ -107,7 +107,16 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 
 struct Rng {
     uint32_t k0, k1, replica, epoch_lo, epoch_hi24;
+#ifdef SSE_PHASE_TIMING
+    uint32_t dbgx;
+#endif
     __device__ __forceinline__ uint4 draw(uint32_t tag, uint32_t index) const {
+#ifdef SSE_PHASE_TIMING // diagnostic builds: dbg bit 1 = cheap hash instead of Philox (timing attribution only)
+        if (dbgx & 2u) {
+            const uint32_t h = (index * 0x9E3779B9u) ^ (epoch_lo * 0x85EBCA6Bu) ^ (replica * 0xC2B2AE35u) ^ tag;
+            return make_uint4(h * 0x27D4EB2Fu, h ^ (h >> 15), h * 0x165667B1u, h ^ (h << 13));
+        }
+#endif
         return philox4x32_10(index, epoch_lo, replica, (tag << 24) | epoch_hi24, k0, k1);
     }
 };
@@ -115,6 +124,9 @@ __device__ __forceinline__ Rng make_rng(const DevBatch &B, uint32_t r, uint64_t 
     Rng g;
     g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.replica_offset + r;
     g.epoch_lo = (uint32_t)epoch; g.epoch_hi24 = (uint32_t)(epoch >> 32) & 0xFFFFFFu;
+#ifdef SSE_PHASE_TIMING
+    g.dbgx = B.dbg_flags;
+#endif
     return g;
 }
 __device__ __forceinline__ double u01(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
@@ -147,6 +159,13 @@ extern __shared__ __align__(16) uint32_t lds_raw[];
 // Tables that OTHER lanes of the same wave write between two reads of one lane need a wavefront-scope fence
 // between the writes and the re-reads (the C++ memory model would otherwise let the compiler reuse the first
 // value).  It emits no instruction: LDS operations of one wave execute in order.
+// Diagnostic builds (-DSSE_PHASE_TIMING) can switch parts of a pass off at run time to attribute time; results are
+// then wrong by construction.  Normal builds compile the switches away.
+#ifdef SSE_PHASE_TIMING
+#define SSE_DBG(B, bit) (((B).dbg_flags & (bit)) != 0u)
+#else
+#define SSE_DBG(B, bit) false
+#endif
 #define SSE_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #define LDSHV(off, i) LDSH(off, i)
 #define LDSWV(off, i) LDSW(off, i)
@@ -212,6 +231,9 @@ __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, ui
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 
+// flip bit 0 of 16-bit element e of the table at word offset off (other waves' tables: 32-bit atomic on the word)
+__device__ __forceinline__ void spin_table_flip(uint32_t off, uint32_t e) { atomicXor(&LDSW(off, e >> 1), 1u << ((e & 1u) * 16u)); }
+
 // slot index of (tile, wave, sub-round j, lane)
 template <int W, int K>
 __device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int lane) {
@@ -222,37 +244,67 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int 
 // Diagonal pass.  Reference: DiagonalUpdater::make_diagonal_update_with_rng_and_state_ref
 // (qmc_traits/diagonal.rs:114-135) with metropolis_single_diagonal_update (:142-191), or the heat-bath
 // rule (qmc_traits/heatbath.rs:149-209) when HB.
+//
+// The slot rule depends on the live operator count n, which makes the sweep sequential in p.  One tile of
+// W*64*K slots is decided by a fixed-point iteration instead: every candidate slot evaluates its rule with
+// n = (count at the tile start) + (net accepted candidates at earlier slots of the tile), starting from "none
+// accepted", until no decision changes.  The fixed point is unique and equal to the sequential result (the
+// decision of slot p only depends on decisions at slots < p), and it is reached in 2 rounds almost always
+// because n moves by a few units inside a tile while the rule compares against M - n ~ 1e4..1e5.
+//
+// Per slot and round the work is: one int->f64 convert, one f64 multiply, two f64 compares (written straight to
+// wave masks), the mask algebra on the scalar unit, and four mbcnt for the prefix counts.  All compares are the
+// IEEE f64 expressions of oracle/sse_oracle.c (built with -ffp-contract=off on both sides).
 template <int W, int K, bool CL, bool HB>
 __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double beta, uint32_t M,
                               int &n_io, int &ntrans_io, uint32_t &gr) {
     constexpr int NT = W * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nwords = B.nwords;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     uint32_t *ops = B.ops + (size_t)r * B.cap;
     const double beta_nb = beta * (double)B.Nb;
     const double hb_bw = beta * B.wtot;
-    const uint32_t o_mycopy = L.o_scopy + wave * nwords;
-
-    for (uint32_t i = tid; i < nwords * W; i += NT) LDSW(L.o_scopy, i) = LDSW(L.o_state, i % nwords);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    // Per-wave spin tables T_w[v] (u16, in the o_cur area the cluster scan uses later): bit 0 = spin of v at the
+    // wave's current position; bits 1.. = lane+1 of an off-diagonal op on v inside the sub-round being resolved.
+    const uint32_t N = B.N, h_my = (uint32_t)wave * N;
+    for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) {
+        const uint32_t v = i % N;
+        LDSH(L.o_cur, i) = (uint16_t)((LDSW(L.o_state, v >> 5) >> (v & 31)) & 1u);
+    }
     __syncthreads();
 
     const uint32_t ntiles = (M + NT * K - 1) / (NT * K);
     int n_start = n_io, ntrans = 0;
 
+    // off-diagonal ops ("events") of a tile's words: variable and flag; Ising bonds: only single-site ops can be
+    // off-diagonal (bit 0 of in^out)
+    auto event_of = [&](uint32_t wd, uint32_t &var) -> bool {
+        const bool ev = ((sse_op_in(wd) ^ sse_op_out(wd)) & 1u) != 0u;
+        var = decode_bond<CL, W>(B, L, ev ? sse_op_bond(wd) : 0u).a;
+        return ev;
+    };
+    // flip the spin of the event variables in the tables of waves [wlo, whi) (wave-uniform bounds)
+    auto propagate = [&](const uint32_t (&var)[K], const bool (&ev)[K], int wlo, int whi) {
+        for (int w2 = wlo; w2 < whi; ++w2) {
+            const uint32_t base = (uint32_t)w2 * N;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (ev[j]) spin_table_flip(L.o_cur, base + var[j]);
+        }
+    };
+
     uint32_t wnext[K];
-    // prologue: tile 0 words; their off-diagonal events go to the copies of later waves
+    // prologue: tile 0 words; their events go to the tables of later waves
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const uint32_t p = slot_of<W, K>(0, wave, j, lane);
         wnext[j] = p < M ? ops[p] : 0u;
     }
+    {
+        uint32_t var[K]; bool ev[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const uint32_t x = (sse_op_in(wnext[j]) ^ sse_op_out(wnext[j])) & 1u;
-        if (x) {
-            const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wnext[j]));
-            for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.a >> 5)), 1u << (d.a & 31));
-        }
+        for (int j = 0; j < K; ++j) ev[j] = event_of(wnext[j], var[j]);
+        propagate(var, ev, wave + 1, W);
     }
     __syncthreads();
 
@@ -262,30 +314,31 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         uint32_t word[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) word[j] = wnext[j];
-        if (tile + 1 < ntiles) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const uint32_t pn = slot_of<W, K>(tile + 1, wave, j, lane);
-                wnext[j] = pn < M ? ops[pn] : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < K; ++j) wnext[j] = 0u;
+        for (int j = 0; j < K; ++j) { // prefetch the next tile (slots >= M read as empty)
+            const uint32_t pn = slot_of<W, K>(tile + 1, wave, j, lane);
+            wnext[j] = pn < M ? ops[pn] : 0u;
         }
 
-        uint32_t bsel[K], sub[K], evA[K], xb[K];
-        double num[K], u[K];
-        int cand[K]; // +1 insertion candidate, -1 removal candidate, 0 none
-        uint64_t trm[K]; // lanes whose (candidate or present) op is a transverse-field op
+        // per slot, kept across the rounds:
+        //   fa, fb : f64 operands of the rule (see the rounds below); fa = +inf when the slot is not a candidate
+        //   cb     : M (insert candidate) or M + 1 (removal candidate), so that the rule's den is cb - n
+        //   cw     : the op word to store when the candidate is accepted (new diagonal op, or 0 for a removal)
+        double fa[K], fb[K];
+        uint32_t cb[K], cw[K], evA[K];
+        bool isevj[K];
+        uint64_t insm[K]; // insert candidates
+        uint32_t trbits = 0; // bit j: the op at stake in sub-round j is a transverse-field op
         uint4 rnd = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
-            const bool valid = p < M;
             const uint32_t wd = word[j];
-            xb[j] = sse_op_in(wd) ^ sse_op_out(wd);
-            const bool is_empty = valid && wd == 0u;
-            const bool is_diag = wd != 0u && xb[j] == 0u;
+            const bool occ = wd != 0u;
+            const uint32_t inb = sse_op_in(wd) & 1u;
+            const bool isev = ((sse_op_in(wd) ^ sse_op_out(wd)) & 1u) != 0u;
+            const bool is_empty = (p < M) & !occ;
+            const bool is_diag = occ & !isev;
             uint32_t r0, r1, r2 = 0;
             if (HB) {
                 rnd = rng.draw(SSE_TAG_HEATBATH, p);
@@ -299,7 +352,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             uint32_t b;
             if (HB) {
                 b = 0;
-                if (wd) b = sse_op_bond(wd);
+                if (occ) b = sse_op_bond(wd);
                 else if (is_empty) {
                     const double c = u01(r2) * B.wtot;
                     uint32_t lo = 0, hi2 = B.Nb;
@@ -307,117 +360,139 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                     b = lo < B.Nb ? lo : B.Nb - 1;
                 }
             } else {
-                b = wd ? sse_op_bond(wd) : __umulhi(r0, B.Nb);
+                b = occ ? sse_op_bond(wd) : __umulhi(r0, B.Nb);
             }
             const Bd d = decode_bond<CL, W>(B, L, b);
-            const uint32_t va = d.a;
+            const uint32_t va = d.a, kind = bd_kind(d);
             const bool two = d.c != SSE_NO_VAR;
             const uint32_t vc = two ? d.c : va;
-            bsel[j] = b;
-            evA[j] = va;
-            trm[j] = __ballot(bd_kind(d) == SSE_BOND_TRANSVERSE);
-            // spin reads (unconditional, safe indices): own copy xor earlier off-diagonal events of this
-            // sub-round.  Ising bonds: only single-site ops can be off-diagonal (bit 0 of in^out).
-            uint32_t sa = (LDSW(o_mycopy, va >> 5) >> (va & 31)) & 1u;
-            uint32_t sc = two ? (LDSW(o_mycopy, vc >> 5) >> (vc & 31)) & 1u : 0u;
-            const bool isev = (xb[j] & 1u) != 0u;
-            const uint64_t ev0 = __ballot(isev);
-            uint64_t m = ev0;
-            while (m) {
-                const int Ls = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const uint32_t vL = __builtin_amdgcn_readlane(va, Ls);
-                const bool later = lane > Ls;
-                sa ^= (uint32_t)(later & (va == vL));
-                sc ^= (uint32_t)(later & two & (vc == vL));
+            evA[j] = va; isevj[j] = isev;
+            trbits |= (kind == SSE_BOND_TRANSVERSE) ? (1u << j) : 0u;
+            // Spins at this slot = table value, corrected for the off-diagonal ops at EARLIER lanes of this
+            // sub-round.  The op word itself carries the spin before (in) and after (out), so the event lanes
+            // publish (lane+1, in) in the table, everybody reads, then they store the spin after their op.  Two
+            // events on one variable inside a sub-round are rare; a serial loop over the event lanes handles them.
+            const uint64_t ev0 = SSE_DBG(B, 16u) ? 0ull : __ballot(isev);
+            if (ev0) {
+                if (isev) LDSH(L.o_cur, h_my + va) = (uint16_t)((((uint32_t)lane + 1u) << 1) | inb);
+                SSE_WAVE_FENCE();
             }
-            // this sub-round's events become visible to the wave's later sub-rounds
-            if (K > 1 && ev0 && isev) atomicXor(&LDSW(o_mycopy, va >> 5), 1u << (va & 31));
-            sub[j] = sa | (sc << 1);
-            const double w_ins = bond_weight(d, sub[j], sub[j]);
-            const double w_rem = bond_weight(d, sse_op_in(wd), sse_op_in(wd));
+            const uint32_t ea = LDSH(L.o_cur, h_my + va), ec = LDSH(L.o_cur, h_my + vc);
+            uint32_t sa = ea & 1u, sc = ec & 1u;
+            if (ev0) {
+                const uint32_t La = ea >> 1, Lc = ec >> 1;
+                const uint64_t dup = __ballot(isev & (La != (uint32_t)lane + 1u));
+                if (!dup) {
+                    sa ^= (uint32_t)((La - 1u) < (uint32_t)lane); // La == 0: no event on the variable
+                    sc ^= (uint32_t)((Lc - 1u) < (uint32_t)lane);
+                    SSE_WAVE_FENCE();
+                    if (isev) LDSH(L.o_cur, h_my + va) = (uint16_t)(inb ^ 1u);
+                } else {
+                    bool seen_a = false, seen_c = false;
+                    uint64_t m = ev0;
+                    while (m) {
+                        const int Ls = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const uint32_t vL = __builtin_amdgcn_readlane(va, Ls);
+                        const uint32_t inL = __builtin_amdgcn_readlane(inb, Ls);
+                        const bool later = lane > Ls;
+                        if (va == vL) { sa = later ? (inL ^ 1u) : (seen_a ? sa : inL); seen_a = true; }
+                        if (vc == vL) { sc = later ? (inL ^ 1u) : (seen_c ? sc : inL); seen_c = true; }
+                        if (lane == Ls) LDSH(L.o_cur, h_my + va) = (uint16_t)(inL ^ 1u); // in order: the last event wins
+                    }
+                    SSE_WAVE_FENCE();
+                }
+            }
+            const uint32_t sub = sa | (two ? (sc << 1) : 0u);
+            // weight of the diagonal op this slot would get (qmc_ising.rs:863-888); an op already in the string has
+            // its bond's weight (it was inserted with non-zero weight and the string is consistent)
+            const double w_ins = bond_weight(d, sub, sub);
+            const double w = is_empty ? w_ins : d.w;
+            const double uacc = u01(HB ? r0 : r1);
+            bool ins;
             if (HB) {
-                cand[j] = is_empty ? ((u01(r1) * d.w < w_ins) ? 1 : 0) : (is_diag ? -1 : 0);
-                num[j] = 0.0;
-                u[j] = u01(r0);
+                // insert: u*(den + bW) < bW after the bond was chosen and kept with u1*maxw < w (heatbath.rs:163-193)
+                ins = is_empty & (u01(r1) * d.w < w_ins);
+                fa[j] = (ins | is_diag) ? uacc : inf;
+                fb[j] = 0.0;
             } else {
-                cand[j] = is_empty ? (w_ins > 0.0 ? 1 : 0) : (is_diag ? -1 : 0);
-                num[j] = beta_nb * (is_empty ? w_ins : w_rem);
-                u[j] = u01(r1);
+                const double num = beta_nb * w;
+                ins = is_empty & (w_ins > 0.0);
+                // insert: u*den < num          (fa = u, fb = num)
+                // remove: u*num < den          (fa = u*num)
+                fa[j] = ins ? uacc : (is_diag ? uacc * num : inf);
+                fb[j] = num;
             }
+            insm[j] = __ballot(ins);
+            cb[j] = M + (ins ? 0u : 1u);
+            cw[j] = ins ? sse_op_make(b, sub, sub) : 0u;
         }
 
         SSE_STAMP(8);
         // ---- fixed point on n ----
-        int npref[K], dec[K], dec_prev[K];
+        int npref[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) { npref[j] = n_start; dec_prev[j] = 2; dec[j] = 0; }
+        for (int j = 0; j < K; ++j) npref[j] = n_start;
+        uint64_t acc[K], accp[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) accp[j] = 0ull;
         int tot_all = 0;
         bool first = true;
-        uint64_t im[K], rm[K];
         for (;;) {
-            bool changed = false;
             int wtot = 0;
+            bool changed = first;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                int d = 0;
-                if (cand[j] > 0) {
-                    const double den = (double)((int)M - npref[j]);
-                    if (HB) d = (u[j] * (den + hb_bw) < hb_bw) ? 1 : 0;
-                    else d = (u[j] * den < num[j]) ? 1 : 0;
-                } else if (cand[j] < 0) {
-                    const double den = (double)((int)M - npref[j] + 1);
-                    if (HB) d = (u[j] * (den + hb_bw) < den) ? -1 : 0;
-                    else d = (u[j] * num[j] < den) ? -1 : 0;
+                const double t = (double)(int)(cb[j] - (uint32_t)npref[j]); // den of the rule
+                uint64_t lt_ins, lt_rem;
+                if (HB) {
+                    const double lhs = fa[j] * (t + hb_bw);
+                    lt_ins = __ballot(lhs < hb_bw);
+                    lt_rem = __ballot(lhs < t);
+                } else {
+                    lt_ins = __ballot(fa[j] * t < fb[j]);
+                    lt_rem = __ballot(fa[j] < t);
                 }
-                dec[j] = d;
-                changed |= (d != dec_prev[j]);
-                im[j] = __ballot(d > 0);
-                rm[j] = __ballot(d < 0);
-                wtot += popc64(im[j]) - popc64(rm[j]);
+                acc[j] = (lt_ins & insm[j]) | (lt_rem & ~insm[j]);
+                changed |= acc[j] != accp[j];
+                wtot += popc64(acc[j] & insm[j]) - popc64(acc[j] & ~insm[j]);
             }
-            const uint64_t cm = __ballot(changed);
             const int buf = gr & 1;
-            if (lane == 0) { LDSI(L.o_tot, buf * W + wave) = wtot; LDSW(L.o_chg, buf * W + wave) = cm != 0ull; }
+            if (lane == 0) { LDSI(L.o_tot, buf * W + wave) = wtot; LDSW(L.o_chg, buf * W + wave) = changed ? 1u : 0u; }
             __syncthreads();
-            if (first) {
-                first = false;
-                // events of this tile -> copies of earlier waves (all readers of this tile are done);
-                // for K == 1 also the wave's own copy
+            if (first && !SSE_DBG(B, 8u)) {
+                // events of this tile -> tables of earlier waves (all readers of this tile are done);
+                // events of the next tile -> tables of later waves (visible after the next barrier)
+                propagate(evA, isevj, 0, wave);
+                uint32_t var[K]; bool ev[K];
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int wend = (K > 1) ? wave : wave + 1;
-                    if (xb[j] & 1u) for (int w2 = 0; w2 < wend; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (evA[j] >> 5)), 1u << (evA[j] & 31));
-                }
-                // events of the next tile -> copies of later waves (visible after the next barrier)
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const uint32_t xn = (sse_op_in(wnext[j]) ^ sse_op_out(wnext[j])) & 1u;
-                    if (xn) {
-                        const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wnext[j]));
-                        for (int w2 = wave + 1; w2 < W; ++w2) atomicXor(&LDSW(L.o_scopy, w2 * nwords + (d.a >> 5)), 1u << (d.a & 31));
-                    }
-                }
+                for (int j = 0; j < K; ++j) ev[j] = event_of(wnext[j], var[j]);
+                propagate(var, ev, wave + 1, W);
             }
+            // every lane reads the same words: move them to scalar registers so that the loop stays wave-uniform
+            // (the compiler cannot see that an LDS value is the same in all lanes)
             int base = 0; tot_all = 0; uint32_t anychg = 0;
 #pragma unroll
             for (int w2 = 0; w2 < W; ++w2) {
-                const int t = LDSI(L.o_tot, buf * W + w2);
+                const int t = __builtin_amdgcn_readfirstlane(LDSI(L.o_tot, buf * W + w2));
                 if (w2 < wave) base += t;
                 tot_all += t;
-                anychg |= LDSW(L.o_chg, buf * W + w2);
+                anychg |= (uint32_t)__builtin_amdgcn_readfirstlane((int)LDSW(L.o_chg, buf * W + w2));
             }
             gr++;
 #ifdef SSE_PHASE_TIMING
             if (threadIdx.x == 0) B.dbg[(size_t)r * 16 + 13] += 1; // rounds
 #endif
-            if (dec_prev[0] != 2 && !anychg) break;
+            if (SSE_DBG(B, 4u)) break;
+            if (!first && !anychg) break;
+            first = false;
             int run = n_start + base;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                npref[j] = run + popc64(im[j] & lanemask_lt(lane)) - popc64(rm[j] & lanemask_lt(lane));
-                run += popc64(im[j]) - popc64(rm[j]);
-                dec_prev[j] = dec[j];
+                const uint64_t im = acc[j] & insm[j], rm = acc[j] & ~insm[j];
+                npref[j] = run + popc64(im & lanemask_lt(lane)) - popc64(rm & lanemask_lt(lane));
+                run += popc64(im) - popc64(rm);
+                accp[j] = acc[j];
             }
         }
         SSE_STAMP(9);
@@ -428,12 +503,11 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         int dn = 0, dtr = 0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if (dec[j] != 0) {
-                const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
-                ops[p] = dec[j] > 0 ? sse_op_make(bsel[j], sub[j], sub[j]) : 0u;
-            }
-            dn += popc64(im[j]) - popc64(rm[j]);
-            dtr += popc64(im[j] & trm[j]) - popc64(rm[j] & trm[j]);
+            if ((acc[j] >> lane) & 1ull) ops[slot_of<W, K>(tile, wave, j, lane)] = cw[j];
+            const uint64_t im = acc[j] & insm[j], rm = acc[j] & ~insm[j];
+            const uint64_t trm = __ballot((trbits >> j) & 1u);
+            dn += popc64(im) - popc64(rm);
+            dtr += popc64(im & trm) - popc64(rm & trm);
         }
         ntrans += dtr;
         if (lane == 0 && (dtr | dn)) { // a wave's 64*K slots of a tile lie inside one chunk (CH is a multiple of 256 >= 64*K)
@@ -535,7 +609,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                                              uint32_t C) {
     constexpr int NT = W * 64;
     constexpr uint32_t TS = 64 * K; // slots per wave-tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t N = B.N;
     uint32_t *ops = B.ops + (size_t)r * B.cap;
     const uint32_t h_mycur = (uint32_t)wave * N; // 16-bit element offset of this wave's table inside o_cur
@@ -621,11 +695,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                     atomicOr(&LDSW(L.o_touch, va >> 5), 1u << (va & 31));
                     atomicOr(&LDSW(L.o_touch, vc >> 5), 1u << (vc & 31));
                 }
-#ifdef SSE_PHASE_TIMING
-                if (two && !(B.dbg_flags & 1u)) uf_union(uf, seg_a, seg_c); // diagnostic builds: bit 0 = time the scan without unions
-#else
-                if (two) uf_union(uf, seg_a, seg_c);
-#endif
+                if (two & !SSE_DBG(B, 1u)) uf_union(uf, seg_a, seg_c); // diagnostic builds: bit 0 = time the scan without unions
                 if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
                 if constexpr (!G) { // ids fit 16 bits on this path: remember them for the apply pass
                     const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
@@ -835,7 +905,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
                               uint32_t &err) {
     constexpr int NT = W * 64;
     constexpr int U = 4; // independent loads in flight per thread during searches
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     uint32_t *ops = B.ops + (size_t)r * B.cap;
     if (n == 0) return 0u;
     const uint4 o0 = rng.draw(SSE_TAG_LOOP, 0u);
@@ -990,11 +1060,21 @@ namespace sse {
 // QmcStepper::timesteps_measure_with_self (qmc_traits/qmc_stepper.rs:133-162).
 // PHASE only tags the symbol (0 = measured path, 1 = data preparation) so that profilers can tell the
 // two apart; the code is identical.
+// PASSES selects what is compiled in: SSE_PASSES_ALL = every pass (one launch runs whole timesteps), SSE_PASSES_DIAG =
+// the diagonal pass alone.  The diagonal pass needs half the registers and a quarter of the LDS of the cluster
+// pass, so as its own kernel it runs at twice the occupancy (4 waves per SIMD for W <= 4); the host then issues
+// two launches per timestep (isingmc_hip.hip, run()).  n, cutoff, epoch, chunk counters travel through HBM.
 #ifndef SSE_MIN_WAVES_PER_SIMD
 #define SSE_MIN_WAVES_PER_SIMD 1
 #endif
-template <int W, int K, bool CL, int PHASE>
-__global__ __launch_bounds__(W * 64, (W == 8 ? SSE_MIN_WAVES_PER_SIMD : (W == 6 ? 3 : 1))) void sweep_kernel(DevBatch B, SweepArgs A) {
+enum { SSE_PASSES_ALL = 0, SSE_PASSES_DIAG = 1 };
+template <int W, int PASSES>
+constexpr int sse_waves_per_simd() {
+    if (PASSES == SSE_PASSES_DIAG) return W <= 4 ? 4 : (W <= 8 ? 2 : 1);
+    return W == 8 ? SSE_MIN_WAVES_PER_SIMD : (W == 6 ? 3 : (W == 4 ? 2 : 1));
+}
+template <int W, int K, bool CL, int PHASE, int PASSES>
+__global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void sweep_kernel(DevBatch B, SweepArgs A) {
     constexpr int NT = W * 64;
     Lds<W> L;
     L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u, B.has_long);
@@ -1023,6 +1103,7 @@ __global__ __launch_bounds__(W * 64, (W == 8 ? SSE_MIN_WAVES_PER_SIMD : (W == 6 
                 if (want > M) { if (want > B.cap) { err = 1u; break; } M = want; }
             }
         }
+        if constexpr (PASSES == SSE_PASSES_ALL) {
         if (A.domask & SSE_DO_RVB) { // qmc_ising.rs:705-752
             const uint32_t updates = A.rvb_updates ? A.rvb_updates : (B.N + 1u) / 2u;
             last_out = rvb_pass<W, CL>(B, L, r, epoch, M, updates, gr, err);
@@ -1064,9 +1145,11 @@ __global__ __launch_bounds__(W * 64, (W == 8 ? SSE_MIN_WAVES_PER_SIMD : (W == 6 
             a0 += (uint64_t)n; a1 += 1; a2 += (uint64_t)(mag < 0 ? -mag : mag); a3 += (uint64_t)(mag * mag); a6 += (uint64_t)ntrans;
             __syncthreads();
         }
+        } // PASSES == SSE_PASSES_ALL
     }
     __syncthreads();
-    for (uint32_t i = tid; i < B.nwords; i += NT) B.state[(size_t)r * B.nwords + i] = LDSW(L.o_state, i);
+    if constexpr (PASSES == SSE_PASSES_ALL)
+        for (uint32_t i = tid; i < B.nwords; i += NT) B.state[(size_t)r * B.nwords + i] = LDSW(L.o_state, i);
     for (uint32_t i = tid; i < 2 * SSE_MAX_CHUNKS; i += NT) B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i] = LDSW(L.o_chn, i);
     if (tid == 0) {
         B.n[r] = (uint32_t)n; B.ntrans[r] = (uint32_t)ntrans; B.cutoff[r] = M; B.err[r] = err; B.epoch[r] = epoch;
@@ -1077,7 +1160,7 @@ __global__ __launch_bounds__(W * 64, (W == 8 ? SSE_MIN_WAVES_PER_SIMD : (W == 6 
 }
 
 struct LaunchCfg {
-    uint32_t W, K, CL, phase;
+    uint32_t W, K, CL, phase, passes;
     size_t lds_bytes;
     hipStream_t stream;
 };
@@ -1088,26 +1171,31 @@ hipError_t launch_sweep_w6(const LaunchCfg &c, const DevBatch &B, const SweepArg
 hipError_t launch_sweep_w8(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_w16(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 
-template <int W, int K, bool CL, int PHASE>
+template <int W, int K, bool CL, int PHASE, int PASSES>
 hipError_t launch_one(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel<W, K, CL, PHASE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel<W, K, CL, PHASE, PASSES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_kernel<W, K, CL, PHASE>), dim3(B.R), dim3(W * 64), c.lds_bytes, c.stream, B, A);
+    hipLaunchKernelGGL((sweep_kernel<W, K, CL, PHASE, PASSES>), dim3(B.R), dim3(W * 64), c.lds_bytes, c.stream, B, A);
     return hipGetLastError();
+}
+template <int W, int K, bool CL>
+hipError_t launch_k(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
+    if (c.passes == SSE_PASSES_DIAG) {
+        if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_DIAG>(c, B, A);
+        return launch_one<W, K, CL, 0, SSE_PASSES_DIAG>(c, B, A);
+    }
+    if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_ALL>(c, B, A); // data-preparation symbol: default geometry only
+    return launch_one<W, K, CL, 0, SSE_PASSES_ALL>(c, B, A);
 }
 template <int W>
 hipError_t launch_w(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
-    if (c.phase) { // data-preparation symbol: only the default geometry
-        if (c.K == 4 && c.CL) return launch_one<W, 4, true, 1>(c, B, A);
-        if (c.K == 4 && !c.CL) return launch_one<W, 4, false, 1>(c, B, A);
-    }
-    if (c.K == 4 && c.CL) return launch_one<W, 4, true, 0>(c, B, A);
-    if (c.K == 4 && !c.CL) return launch_one<W, 4, false, 0>(c, B, A);
-    if (c.K == 1 && c.CL) return launch_one<W, 1, true, 0>(c, B, A);
-    if (c.K == 1 && !c.CL) return launch_one<W, 1, false, 0>(c, B, A);
-    if (c.K == 2 && c.CL) return launch_one<W, 2, true, 0>(c, B, A);
-    if (c.K == 2 && !c.CL) return launch_one<W, 2, false, 0>(c, B, A);
+    if (c.K == 4 && c.CL) return launch_k<W, 4, true>(c, B, A);
+    if (c.K == 4 && !c.CL) return launch_k<W, 4, false>(c, B, A);
+    if (c.K == 1 && c.CL) return launch_k<W, 1, true>(c, B, A);
+    if (c.K == 1 && !c.CL) return launch_k<W, 1, false>(c, B, A);
+    if (c.K == 2 && c.CL) return launch_k<W, 2, true>(c, B, A);
+    if (c.K == 2 && !c.CL) return launch_k<W, 2, false>(c, B, A);
     return hipErrorInvalidValue;
 }
 

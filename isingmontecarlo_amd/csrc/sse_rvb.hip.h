@@ -379,7 +379,7 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
                                            uint32_t M, uint32_t &gr) {
     constexpr int NT = W * 64;
     constexpr int U = 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t *ops = B.ops + (size_t)r * B.cap;
     const uint32_t last = until < M ? until : M - 1; // inclusive
     uint32_t glen = 0, next = gp;

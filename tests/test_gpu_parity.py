@@ -114,7 +114,7 @@ def test_loop_update_matches(oracle, waves, k, cfgf):
     assert g.verify().all()
 
 
-@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (16, 4, 0), (8, 4, 1)])
+@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (16, 4, 0), (8, 4, 1), (4, 4, 2), (8, 2, 3)])  # cfgf 2 = fused launches
 def test_medium_lattice_many_replicas(oracle, waves, k, cfgf):
     edges = lat.two_d_ferro(16)
     R = 16

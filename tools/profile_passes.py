@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import _lattices as lat
 import isingmontecarlo_amd as im
+if os.environ.get("ISINGMC_HIP_LIB"):  # timing-experiment builds (tools/experiment_build.py)
+    im._build.LIB = os.environ["ISINGMC_HIP_LIB"]; im._build.build = lambda *a, **k: im._build.LIB
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--L", type=int, default=32); ap.add_argument("--beta", type=float, default=16.0)
