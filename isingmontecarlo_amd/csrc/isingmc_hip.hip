@@ -83,7 +83,7 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
     uint32_t *s = scratch_state + (size_t)r * B.nwords;
     const uint32_t *s0 = B.state + (size_t)r * B.nwords;
     for (uint32_t i = 0; i < B.nwords; ++i) s[i] = s0[i];
-    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t M = B.cutoff[r];
     bool good = true;
     uint32_t count = 0, ntr = 0, ccn = 0, cctr = 0;
@@ -125,7 +125,7 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
 }
 
 static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges) {
-    return (size_t)nwords * (W + 2) + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + 64 * W + ledges + ((size_t)W * N + 1) / 2;
+    return (size_t)nwords * (W + 2) + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + 64 * W + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
 }
 
 // LDS footprint of the next launch.  The union-find of the cluster pass lives in LDS as 16-bit parents when all
@@ -363,10 +363,17 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
     D.nchunks = (D.cap + D.CH - 1) / D.CH;
     b->W = W; b->K = K; b->CL = CL ? 1u : 0u;
+    { // row stride: whole tiles, plus room for the (unused) prefetch of a cluster-scan wave whose chunk range is empty
+        const size_t tile = (size_t)W * 64 * K;
+        const size_t need1 = ((size_t)D.cap + tile - 1) / tile * tile;
+        const size_t need2 = ((size_t)D.cap + D.CH - 1) / D.CH * D.CH + 256;
+        const size_t need = need1 > need2 ? need1 : need2;
+        D.stride = (uint32_t)((need + tile - 1) / tile * tile);
+    }
     b->lds_fixed_words_ = fixed; b->lds_total_words = total_words; b->uf_ids_limit = cfg->lds_uf_ids_limit;
     { // the RVB pass reuses everything from the scan tables on: launches that run it get enough LDS for its scratch
       // and constant-op table (other launches keep the smaller footprint, which decides workgroups per CU)
-        const size_t o_cur = fixed - ((size_t)W * D.N + 1) / 2;
+        const size_t o_cur = fixed - ((size_t)W * D.N + 1) / 2 - ((size_t)W * D.N + 3) / 4;
         const size_t want = 4 * (o_cur + 2 + rvb_fixed_words(D.N, D.E) + (size_t)D.cap);
         b->lds_bytes_rvb = (want < (size_t)max_lds ? want : (size_t)max_lds) & ~(size_t)7;
     }
@@ -375,7 +382,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     D.has_long = has_long ? 1u : 0u;
 
     int rc;
-    if ((rc = dalloc(b, &D.ops, (size_t)D.R * D.cap))) return fail(rc);
+    if ((rc = dalloc(b, &D.ops, (size_t)D.R * D.stride))) return fail(rc);
     if ((rc = dalloc(b, &D.state, (size_t)D.R * D.nwords))) return fail(rc);
     if ((rc = dalloc(b, &D.n, D.R))) return fail(rc);
     if ((rc = dalloc(b, &D.ntrans, D.R))) return fail(rc);
@@ -393,7 +400,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         D.acc_row = b->d_acc_row;
     }
     if ((rc = dalloc(b, &D.chunks, (size_t)D.R * 2 * SSE_MAX_CHUNKS))) return fail(rc);
-    if ((rc = dalloc(b, &D.segs, (size_t)D.R * D.cap, false))) return fail(rc);
+    if ((rc = dalloc(b, &D.segs, (size_t)D.R * D.stride, false))) return fail(rc);
     if ((rc = dalloc(b, &D.dbg, (size_t)D.R * 16))) return fail(rc);
     BondRec *dbonds = nullptr; double *dcum = nullptr;
     if ((rc = dalloc(b, &dbonds, D.Nb, false))) return fail(rc);
@@ -638,7 +645,7 @@ int isingmc_set_cutoff(isingmc_batch *b, uint32_t r, uint32_t cutoff) {
 int isingmc_export_ops(isingmc_batch *b, uint32_t r, uint32_t *words, uint32_t nwords) {
     if (!b || !words || r >= b->dev.R || nwords > b->dev.cap) { if (b) b->err = "bad arguments to export_ops"; return ISINGMC_EINVAL; }
     HIP_TRY(b, hipSetDevice(b->device));
-    HIP_TRY(b, hipMemcpy(words, b->dev.ops + (size_t)r * b->dev.cap, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost));
+    HIP_TRY(b, hipMemcpy(words, b->dev.ops + (size_t)r * b->dev.stride, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost));
     return ISINGMC_OK;
 }
 int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint32_t nwords) {
@@ -659,8 +666,8 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
         if (((b->bonds_host[bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK) == SSE_BOND_TRANSVERSE) { ntr++; chunks[SSE_MAX_CHUNKS + p / b->dev.CH]++; }
     }
     HIP_TRY(b, hipSetDevice(b->device));
-    uint32_t *dst = b->dev.ops + (size_t)r * b->dev.cap;
-    HIP_TRY(b, hipMemset(dst, 0, sizeof(uint32_t) * b->dev.cap));
+    uint32_t *dst = b->dev.ops + (size_t)r * b->dev.stride;
+    HIP_TRY(b, hipMemset(dst, 0, sizeof(uint32_t) * b->dev.stride));
     if (nwords) HIP_TRY(b, hipMemcpy(dst, words, sizeof(uint32_t) * nwords, hipMemcpyHostToDevice));
     uint32_t cur = 0;
     HIP_TRY(b, hipMemcpy(&cur, b->dev.cutoff + r, 4, hipMemcpyDeviceToHost));

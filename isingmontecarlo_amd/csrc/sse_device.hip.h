@@ -36,6 +36,8 @@ struct BondRec {       // 16 B, one dwordx4 load (general table, any N / E)
 
 struct DevBatch {
     uint32_t R, N, E, Nb, cap, nwords;
+    uint32_t stride;      // words between the op-strings (and segment-id rows) of consecutive replicas: cap rounded up to
+                          // a whole number of tiles, so that full-tile loads and stores never leave the row; slots >= cutoff hold 0
     uint32_t *ops;        // [R][cap]
     uint32_t *state;      // [R][nwords] bit v of word v>>5
     uint32_t *n, *ntrans, *cutoff, *err, *aux;  // [R]
@@ -156,6 +158,7 @@ extern __shared__ __align__(16) uint32_t lds_raw[];
 #define LDSW(off, i) lds_raw[(off) + (i)]
 #define LDSI(off, i) (reinterpret_cast<int &>(lds_raw[(off) + (i)]))
 #define LDSH(off, i) (reinterpret_cast<uint16_t *>(lds_raw)[2u * (off) + (i)]) // 16-bit element i of the array at word offset off
+#define LDSB(off, i) (reinterpret_cast<uint8_t *>(lds_raw)[4u * (off) + (i)])  // 8-bit element i of the array at word offset off
 // Tables that OTHER lanes of the same wave write between two reads of one lane need a wavefront-scope fence
 // between the writes and the re-reads (the C++ memory model would otherwise let the compiler reuse the first
 // value).  It emits no instruction: LDS operations of one wave execute in order.
@@ -183,6 +186,7 @@ struct Lds {           // word offsets into lds_raw
     uint32_t o_cutlane; // [W][64]      per wave: lane of the k-th cut of the current sub-round
     uint32_t o_edges;  // [E]           compact edge table (CL mode only)
     uint32_t o_cur;    // [W][N] u16    per wave: rank+1 (within the wave's range) of the latest cut on each variable
+    uint32_t o_cl;     // [W][N] u8     per wave: 1 + rank inside the current sub-round of a cut on the variable (0 = none)
     uint32_t o_frozen; // [ufwords]     bit per id: segment holds a longitudinal op
     uint32_t o_froot;  // [ufwords]     bit per id: root is frozen
     uint32_t o_parent; // [ufcap] u16 (the LDS union-find is only used when every id fits 16 bits)
@@ -199,6 +203,7 @@ struct Lds {           // word offsets into lds_raw
         o_cutlane = base; base += W * 64;
         o_edges = base; base += ledges;
         o_cur = base; base += (W * N + 1) / 2;
+        o_cl = base; base += (W * N + 3) / 4;
         o_frozen = base; base += has_long ? (ufcap + 31) / 32 : 0u;
         o_froot = base; base += has_long ? (ufcap + 31) / 32 : 0u;
         o_parent = base;
@@ -219,7 +224,13 @@ __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, ui
         d.c = two ? ((e >> 15) & SSE_CE_VAR_MASK) : SSE_NO_VAR;
         d.kp = two ? (SSE_BOND_TWO_SITE | (((e >> 30) & 1u) << 2))
                    : (tr ? SSE_BOND_TRANSVERSE : (SSE_BOND_LONGITUDINAL | (B.hpos << 2)));
-        d.w = two ? B.wJ : (tr ? B.gamma : B.wh); // CL mode is only selected for uniform |J| (scalar weights)
+        // CL mode is only selected for uniform |J|: the three weights are scalars.  Select on their halves held in
+        // scalar registers; written as a select of the doubles the compiler turns it into a per-lane LOAD from the
+        // kernel-argument segment, whose s_waitcnt then also waits for the op-word prefetch (vmcnt is in order).
+        const int jlo = __builtin_amdgcn_readfirstlane(__double2loint(B.wJ)), jhi = __builtin_amdgcn_readfirstlane(__double2hiint(B.wJ));
+        const int glo = __builtin_amdgcn_readfirstlane(__double2loint(B.gamma)), ghi = __builtin_amdgcn_readfirstlane(__double2hiint(B.gamma));
+        const int hlo = __builtin_amdgcn_readfirstlane(__double2loint(B.wh)), hhi = __builtin_amdgcn_readfirstlane(__double2hiint(B.wh));
+        d.w = __hiloint2double(two ? jhi : (tr ? ghi : hhi), two ? jlo : (tr ? glo : hlo));
     } else {
         const uint4 q = *reinterpret_cast<const uint4 *>(B.bonds + b);
         d.a = q.x & SSE_VAR_MASK; d.c = q.y; d.kp = q.x >> SSE_INFO_SHIFT;
@@ -260,7 +271,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                               int &n_io, int &ntrans_io, uint32_t &gr) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
-    uint32_t *ops = B.ops + (size_t)r * B.cap;
+    uint32_t *ops = B.ops + (size_t)r * B.stride;
     const double beta_nb = beta * (double)B.Nb;
     const double hb_bw = beta * B.wtot;
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
@@ -293,13 +304,14 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         }
     };
 
+    // Loads and stores of whole tiles are unconditional and branch-free: rows are padded to a whole number of
+    // tiles (DevBatch::stride) and slots >= M hold 0, so a partial last tile reads zeros and writes them back.
+    // (Predicated loads put every access into its own basic block, and the compiler then waits for ALL
+    // outstanding memory operations before the first use — i.e. for the prefetch it has just issued.)
     uint32_t wnext[K];
     // prologue: tile 0 words; their events go to the tables of later waves
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const uint32_t p = slot_of<W, K>(0, wave, j, lane);
-        wnext[j] = p < M ? ops[p] : 0u;
-    }
+    for (int j = 0; j < K; ++j) wnext[j] = ops[slot_of<W, K>(0, wave, j, lane)];
     {
         uint32_t var[K]; bool ev[K];
 #pragma unroll
@@ -314,18 +326,19 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         uint32_t word[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) word[j] = wnext[j];
+        {   // prefetch the next tile (after the last one: the same tile again, the values are not used)
+            const uint32_t tn = tile + 1 < ntiles ? tile + 1 : tile;
 #pragma unroll
-        for (int j = 0; j < K; ++j) { // prefetch the next tile (slots >= M read as empty)
-            const uint32_t pn = slot_of<W, K>(tile + 1, wave, j, lane);
-            wnext[j] = pn < M ? ops[pn] : 0u;
+            for (int j = 0; j < K; ++j) wnext[j] = ops[slot_of<W, K>(tn, wave, j, lane)];
         }
 
         // per slot, kept across the rounds:
         //   fa, fb : f64 operands of the rule (see the rounds below); fa = +inf when the slot is not a candidate
         //   cb     : M (insert candidate) or M + 1 (removal candidate), so that the rule's den is cb - n
-        //   cw     : the op word to store when the candidate is accepted (new diagonal op, or 0 for a removal)
+        //   cw     : the op word to store when the candidate is accepted (new diagonal op, or 0 for a removal);
+        //   keep   : the word to store otherwise (what the slot holds now)
         double fa[K], fb[K];
-        uint32_t cb[K], cw[K], evA[K];
+        uint32_t cb[K], cw[K], keep[K], evA[K];
         bool isevj[K];
         uint64_t insm[K]; // insert candidates
         uint32_t trbits = 0; // bit j: the op at stake in sub-round j is a transverse-field op
@@ -426,6 +439,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             insm[j] = __ballot(ins);
             cb[j] = M + (ins ? 0u : 1u);
             cw[j] = ins ? sse_op_make(b, sub, sub) : 0u;
+            keep[j] = wd;
         }
 
         SSE_STAMP(8);
@@ -464,10 +478,12 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 // events of this tile -> tables of earlier waves (all readers of this tile are done);
                 // events of the next tile -> tables of later waves (visible after the next barrier)
                 propagate(evA, isevj, 0, wave);
-                uint32_t var[K]; bool ev[K];
+                if (tile + 1 < ntiles) {
+                    uint32_t var[K]; bool ev[K];
 #pragma unroll
-                for (int j = 0; j < K; ++j) ev[j] = event_of(wnext[j], var[j]);
-                propagate(var, ev, wave + 1, W);
+                    for (int j = 0; j < K; ++j) ev[j] = event_of(wnext[j], var[j]);
+                    propagate(var, ev, wave + 1, W);
+                }
             }
             // every lane reads the same words: move them to scalar registers so that the loop stays wave-uniform
             // (the compiler cannot see that an LDS value is the same in all lanes)
@@ -503,7 +519,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         int dn = 0, dtr = 0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if ((acc[j] >> lane) & 1ull) ops[slot_of<W, K>(tile, wave, j, lane)] = cw[j];
+            ops[slot_of<W, K>(tile, wave, j, lane)] = ((acc[j] >> lane) & 1ull) ? cw[j] : keep[j];
             const uint64_t im = acc[j] & insm[j], rm = acc[j] & ~insm[j];
             const uint64_t trm = __ballot((trbits >> j) & 1u);
             dn += popc64(im) - popc64(rm);
@@ -611,9 +627,10 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
     constexpr uint32_t TS = 64 * K; // slots per wave-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t N = B.N;
-    uint32_t *ops = B.ops + (size_t)r * B.cap;
-    const uint32_t h_mycur = (uint32_t)wave * N; // 16-bit element offset of this wave's table inside o_cur
+    uint32_t *ops = B.ops + (size_t)r * B.stride;
+    const uint32_t h_mycur = (uint32_t)wave * N; // element offset of this wave's tables inside o_cur / o_cl
     for (uint32_t i = tid; i < ((uint32_t)W * N + 1) / 2; i += NT) LDSW(L.o_cur, i) = 0u;
+    for (uint32_t i = tid; i < ((uint32_t)W * N + 3) / 4; i += NT) LDSW(L.o_cl, i) = 0u;
     __syncthreads();
     // this wave's chunk range and the dense id of its first cut
     const uint32_t used = (M + B.CH - 1) / B.CH;
@@ -622,20 +639,28 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
     uint32_t cutbase = 0;
     for (uint32_t c = lane; c < c0; c += 64) cutbase += LDSW(L.o_chtr, c);
     for (int off = 32; off > 0; off >>= 1) cutbase += __shfl_xor(cutbase, off);
+    cutbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cutbase);
     const uint32_t pbeg = c0 * B.CH, pend = min(c1 * B.CH, M);
     const uint32_t my_placeholder_base = wave == 0 ? 0u : N + C + (uint32_t)(wave - 1) * N;
     const uint32_t idbase = N + cutbase - 1u; // id of the cut with local rank+1 == x is idbase + x
     if (lane == 0) LDSW(L.o_chg, wave) = idbase; // read back by cluster_pass when it joins the ranges
     uint32_t nlocal = 0;                      // cuts seen so far in this wave's range
+    // branch-free prefetch (see diagonal_pass): ranges are whole tiles except at the end of the string, where the
+    // padded row holds zeros; past the range end the last tile is simply read again
     uint32_t wnext[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) { const uint32_t p = pbeg + j * 64 + lane; wnext[j] = p < pend ? ops[p] : 0u; }
+    for (int j = 0; j < K; ++j) wnext[j] = ops[pbeg + j * 64 + lane];
     for (uint32_t p0 = pbeg; p0 < pend; p0 += TS) {
         uint32_t word[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) word[j] = wnext[j];
+        for (int j = 0; j < K; ++j) word[j] = (p0 + j * 64 + lane < pend) ? wnext[j] : 0u;
+        {
+            const uint32_t pn0 = p0 + TS < pend ? p0 + TS : p0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) { const uint32_t pn = p0 + TS + j * 64 + lane; wnext[j] = pn < pend ? ops[pn] : 0u; }
+            for (int j = 0; j < K; ++j) wnext[j] = ops[pn0 + j * 64 + lane];
+        }
+        uint32_t ua[K], uc[K]; // the tile's unions, issued together after the K sub-rounds (unions commute)
+        bool utwo[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             // straight-line, predicated code: every LDS read uses a safe index and is issued unconditionally
@@ -648,29 +673,30 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             const bool iscut = nonempty & (kind == SSE_BOND_TRANSVERSE);
             const uint64_t cutmask = __ballot(iscut);
             const uint32_t first = idbase + nlocal + 1u;
-            const uint32_t id_own = first + popc64(cutmask & lanemask_lt(lane));
+            const uint32_t kown = popc64(cutmask & lanemask_lt(lane)); // cuts of this sub-round at earlier lanes
+            const uint32_t id_own = first + kown;
             // Ordered resolution inside the sub-round: a leg on variable x belongs to the segment of the latest
-            // cut on x at an EARLIER slot.  Fast path (no two cuts of this sub-round share a variable): the cut
-            // lanes publish rank and lane through LDS and every lane compares lanes; otherwise a serial loop
-            // over the cut lanes (ballot + v_readlane) resolves it.
-            SSE_WAVE_FENCE();
-            const uint32_t xa = LDSHV(L.o_cur, h_mycur + va), xc = LDSHV(L.o_cur, h_mycur + vc);
+            // cut on x at an EARLIER slot.  The cut lanes publish 1 + (their rank inside the sub-round) in o_cl;
+            // one round of LDS reads then gives every lane the latest cut before the sub-round (o_cur) and the
+            // cut inside it (o_cl), which precedes the lane iff its rank is below the lane's own count of
+            // earlier cuts.  Two cuts of one sub-round on the same variable are rare: a serial loop over the cut
+            // lanes (ballot + v_readlane) resolves those.
+            if (cutmask) {
+                if (iscut) LDSB(L.o_cl, h_mycur + va) = (uint8_t)(kown + 1u);
+                SSE_WAVE_FENCE();
+            }
+            const uint32_t xa = LDSH(L.o_cur, h_mycur + va), xc = LDSH(L.o_cur, h_mycur + vc);
+            const uint32_t ma = LDSB(L.o_cl, h_mycur + va), mc = LDSB(L.o_cl, h_mycur + vc);
             uint32_t seg_a = xa ? idbase + xa : my_placeholder_base + va;
             uint32_t seg_c = xc ? idbase + xc : my_placeholder_base + vc;
             if (cutmask) {
                 const uint32_t myrank1 = id_own - idbase; // rank+1 of this lane's cut inside the wave's range
-                if (iscut) {
-                    LDSHV(L.o_cur, h_mycur + va) = (uint16_t)myrank1;
-                    LDSWV(L.o_cutlane, wave * 64 + (myrank1 - nlocal - 1u)) = (uint32_t)lane;
-                }
-                SSE_WAVE_FENCE();
-                const uint32_t ya = LDSHV(L.o_cur, h_mycur + va), yc = LDSHV(L.o_cur, h_mycur + vc);
-                const uint64_t dup = __ballot(iscut & (ya != myrank1));
+                const uint64_t dup = __ballot(iscut & (ma != kown + 1u));
                 if (!dup) {
-                    const uint32_t la = LDSWV(L.o_cutlane, wave * 64 + (ya != xa ? ya - nlocal - 1u : 0u));
-                    const uint32_t lc = LDSWV(L.o_cutlane, wave * 64 + (yc != xc ? yc - nlocal - 1u : 0u));
-                    seg_a = ((ya != xa) & (la < (uint32_t)lane)) ? idbase + ya : seg_a;
-                    seg_c = ((yc != xc) & (lc < (uint32_t)lane)) ? idbase + yc : seg_c;
+                    seg_a = ((ma - 1u) < kown) ? first + (ma - 1u) : seg_a; // ma == 0: no cut on the variable
+                    seg_c = ((mc - 1u) < kown) ? first + (mc - 1u) : seg_c;
+                    SSE_WAVE_FENCE();
+                    if (iscut) { LDSH(L.o_cur, h_mycur + va) = (uint16_t)myrank1; LDSB(L.o_cl, h_mycur + va) = (uint8_t)0; }
                 } else {
                     bool lastcut = iscut; // no later cut lane of this sub-round is on the same variable
                     uint64_t m = cutmask;
@@ -685,7 +711,9 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                         lastcut = lastcut & !((lane < Ls) & same_a);
                         idL++;
                     }
-                    if (iscut & lastcut) LDSHV(L.o_cur, h_mycur + va) = (uint16_t)myrank1; // the last cut wins
+                    SSE_WAVE_FENCE();
+                    if (iscut) LDSB(L.o_cl, h_mycur + va) = (uint8_t)0;
+                    if (iscut & lastcut) LDSH(L.o_cur, h_mycur + va) = (uint16_t)myrank1; // the last cut wins
                 }
             }
             nlocal += popc64(cutmask);
@@ -695,11 +723,12 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                     atomicOr(&LDSW(L.o_touch, va >> 5), 1u << (va & 31));
                     atomicOr(&LDSW(L.o_touch, vc >> 5), 1u << (vc & 31));
                 }
-                if (two & !SSE_DBG(B, 1u)) uf_union(uf, seg_a, seg_c); // diagnostic builds: bit 0 = time the scan without unions
+                ua[j] = seg_a; uc[j] = seg_c;
+                utwo[j] = two & !SSE_DBG(B, 1u); // diagnostic builds: bit 0 = time the scan without unions
                 if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
                 if constexpr (!G) { // ids fit 16 bits on this path: remember them for the apply pass
                     const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
-                    B.segs[(size_t)r * B.cap + p0 + j * 64 + lane] = seg_a | (hi << 16);
+                    B.segs[(size_t)r * B.stride + p0 + j * 64 + lane] = seg_a | (hi << 16);
                 }
             } else {
                 const uint32_t fa = uf.get(seg_a), fc = uf.get(seg_c), fo = uf.get(iscut ? id_own : seg_a);
@@ -707,6 +736,18 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                 const uint32_t in = sse_op_in(wd) ^ (fa | f2), out = sse_op_out(wd) ^ (fo | f2);
                 const uint32_t neww = (wd & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
                 if (nonempty & (neww != wd)) ops[p0 + j * 64 + lane] = neww;
+            }
+        }
+        if (!APPLY) {
+            // one overlapped look at both parents of every union: same parent => already one set (the common case
+            // once a big cluster has formed); the rest go through the generic union
+            uint32_t pa[K], pc[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) { pa[j] = uf.get(utwo[j] ? ua[j] : 0u); pc[j] = uf.get(utwo[j] ? uc[j] : 0u); }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const bool need = utwo[j] & (pa[j] != pc[j]);
+                if (__any(need)) { if (need) uf_union(uf, pa[j], pc[j]); }
             }
         }
     }
@@ -720,21 +761,29 @@ template <int W, int K, bool CL>
 __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<false> &uf) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
-    uint32_t *ops = B.ops + (size_t)r * B.cap;
-    const uint32_t *segs = B.segs + (size_t)r * B.cap;
-    for (uint32_t p0 = 0; p0 < M; p0 += (uint32_t)(K * NT)) {
+    uint32_t *ops = B.ops + (size_t)r * B.stride;
+    const uint32_t *segs = B.segs + (size_t)r * B.stride;
+    // software-pipelined stream over whole tiles (branch-free loads and stores, see diagonal_pass): slots >= M are
+    // empty and are written back unchanged
+    constexpr uint32_t TS = (uint32_t)(K * NT);
+    uint32_t wn[K], sn[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { wn[j] = ops[(uint32_t)(j * NT + tid)]; sn[j] = segs[(uint32_t)(j * NT + tid)]; }
+    for (uint32_t p0 = 0; p0 < M; p0 += TS) {
         uint32_t wd[K], sg[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t p = p0 + (uint32_t)(j * NT + tid);
-            wd[j] = p < M ? ops[p] : 0u;
-            sg[j] = p < M ? segs[p] : 0u;
+        for (int j = 0; j < K; ++j) { wd[j] = wn[j]; sg[j] = sn[j]; }
+        {
+            const uint32_t pn0 = p0 + TS < M ? p0 + TS : p0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { wn[j] = ops[pn0 + (uint32_t)(j * NT + tid)]; sn[j] = segs[pn0 + (uint32_t)(j * NT + tid)]; }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const uint32_t w = wd[j];
             const bool nonempty = w != 0u;
-            const uint32_t fa = uf.get(sg[j] & 0xFFFFu), fb = uf.get(sg[j] >> 16);
+            // segment ids of empty slots are stale: read a safe index
+            const uint32_t fa = uf.get(nonempty ? (sg[j] & 0xFFFFu) : 0u), fb = uf.get(nonempty ? (sg[j] >> 16) : 0u);
             bool two;
             if constexpr (CL) two = nonempty & (sse_op_bond(w) < B.E);
             else two = nonempty & (decode_bond<CL, W>(B, L, nonempty ? sse_op_bond(w) : 0u).c != SSE_NO_VAR);
@@ -743,7 +792,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
             const uint32_t in = sse_op_in(w) ^ (two ? (fa | (fb << 1)) : fa);
             const uint32_t out = sse_op_out(w) ^ (two ? (fa | (fb << 1)) : fb);
             const uint32_t neww = (w & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
-            if (nonempty & (neww != w)) ops[p0 + (uint32_t)(j * NT + tid)] = neww;
+            ops[p0 + (uint32_t)(j * NT + tid)] = nonempty ? neww : 0u;
         }
     }
     __syncthreads();
@@ -857,7 +906,7 @@ template <int W, bool CL>
 __device__ __forceinline__ void touch_scan(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
-    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
     for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_touch, i) = 0u;
     __syncthreads();
     for (uint32_t p0 = 0; p0 < M; p0 += 4 * NT) {
@@ -906,7 +955,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
     constexpr int NT = W * 64;
     constexpr int U = 4; // independent loads in flight per thread during searches
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
-    uint32_t *ops = B.ops + (size_t)r * B.cap;
+    uint32_t *ops = B.ops + (size_t)r * B.stride;
     if (n == 0) return 0u;
     const uint4 o0 = rng.draw(SSE_TAG_LOOP, 0u);
     const uint32_t nth = __umulhi(o0.x, (uint32_t)n);

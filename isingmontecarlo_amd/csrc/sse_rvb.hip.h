@@ -310,7 +310,7 @@ __device__ __forceinline__ uint32_t rvb_find_constants(const DevBatch &B, const 
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
     const uint32_t N = B.N;
-    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
     for (uint32_t v = tid; v < N; v += NT) { LDSW(R.o_zero, v) = 0u; LDSH(R.o_v2s, v) = (uint16_t)0xFFFFu; }
     if (R.adj_lds) {
         for (uint32_t v = tid; v <= N; v += NT) LDSH(R.o_adjs, v) = (uint16_t)B.adj_start[v];
@@ -380,7 +380,7 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
     constexpr int NT = W * 64;
     constexpr int U = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
-    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t last = until < M ? until : M - 1; // inclusive
     uint32_t glen = 0, next = gp;
     while (M != 0u && next <= last) {
@@ -439,7 +439,7 @@ __device__ __forceinline__ void rvb_state_at(const DevBatch &B, const Lds<W> &L,
     constexpr int NT = W * 64;
     constexpr int U = 4;
     const int tid = threadIdx.x;
-    const uint32_t *ops = B.ops + (size_t)r * B.cap;
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
     for (uint32_t s = tid; s < nsub; s += NT) LDSW(R.o_last, s) = 0u;
     if (tid == 0) LDSW(R.o_ctl, RC_SKIP) = 0u;
     __syncthreads();
@@ -493,7 +493,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
                                              uint32_t &gr, uint32_t &err) {
     const int tid = threadIdx.x;
     const uint32_t N = B.N;
-    uint32_t *ops = B.ops + (size_t)r * B.cap;
+    uint32_t *ops = B.ops + (size_t)r * B.stride;
     RvbLds R;
     rvb_carve<W>(R, L, B);
     if (tid == 0) LDSW(R.o_ctl, RC_ERR) = 0u;
