@@ -218,6 +218,8 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     const uint32_t diag_bits = SSE_DO_DIAG | SSE_DO_HEATBATH | SSE_DO_GROW;
     const bool split = !b->fused_launch && (A.domask & SSE_DO_DIAG);
     size_t timed_steps = 0; // split path: steps whose launches carry events
+    // launches without a diagonal or RVB pass use the kernel that leaves that code out
+    if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB)) || (split && !(A.domask & SSE_DO_RVB))) lc.passes = SSE_PASSES_OFFDIAG;
     HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
     if (!split) {
         const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;

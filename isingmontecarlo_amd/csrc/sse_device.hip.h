@@ -611,6 +611,20 @@ __device__ __forceinline__ void uf_union(const UFA<G> &uf, uint32_t a, uint32_t 
     }
 }
 
+// Union on trees that only the calling wave touches (cluster scan): plain stores; lanes that hook the same root in
+// one instruction are detected by reading the parent back.
+__device__ __forceinline__ void uf_union_wave(const UFA<false> &uf, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = uf_find(uf, a);
+        b = uf_find(uf, b);
+        if (a == b) return;
+        if (a > b) { const uint32_t t = a; a = b; b = t; }
+        uf.set(b, a);
+        SSE_WAVE_FENCE();
+        if (uf.get(b) == a) return;
+    }
+}
+
 // Segment scan shared by cluster build and apply.  BARRIER-FREE: wave w owns a contiguous range of chunks of
 // the op-string and scans it alone, in p order, with its own copy of the "latest cut per variable" table.
 // Segment ids (min-root union-find => canonical label = smallest id of a cluster):
@@ -738,16 +752,46 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                 if (nonempty & (neww != wd)) ops[p0 + j * 64 + lane] = neww;
             }
         }
-        if (!APPLY) {
-            // one overlapped look at both parents of every union: same parent => already one set (the common case
-            // once a big cluster has formed); the rest go through the generic union
-            uint32_t pa[K], pc[K];
+        if constexpr (!APPLY) {
+            if constexpr (G) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) { pa[j] = uf.get(utwo[j] ? ua[j] : 0u); pc[j] = uf.get(utwo[j] ? uc[j] : 0u); }
+                for (int j = 0; j < K; ++j) if (utwo[j]) uf_union(uf, ua[j], uc[j]);
+            } else {
+                // During the scan every wave only touches ids of its own range (its cuts and its placeholders), so
+                // its trees are private until the ranges are joined: no atomics are needed, lanes of the wave that
+                // hook the same root in one store instruction are sorted out by reading the parent back.  The K
+                // unions of the tile go together, three overlapped LDS rounds for all of them: parents, grand-
+                // parents (root test + halving), read-back of the links.  All reads of a batch precede all its
+                // stores, so every lane decides on the same snapshot; a link that another lane overwrote (same
+                // root hooked twice) or a chain deeper than two falls back to the serial routine.
+                uint32_t pa[K], pc[K], ga[K], gc[K], hi[K], lo[K];
+                bool link[K], slow[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const bool need = utwo[j] & (pa[j] != pc[j]);
-                if (__any(need)) { if (need) uf_union(uf, pa[j], pc[j]); }
+                for (int j = 0; j < K; ++j) { pa[j] = uf.get(utwo[j] ? ua[j] : 0u); pc[j] = uf.get(utwo[j] ? uc[j] : 0u); }
+#pragma unroll
+                for (int j = 0; j < K; ++j) { ga[j] = uf.get(pa[j]); gc[j] = uf.get(pc[j]); }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const bool differ = utwo[j] & (pa[j] != pc[j]); // same parent: one set already
+                    const bool roots = (ga[j] == pa[j]) & (gc[j] == pc[j]);
+                    link[j] = differ & roots;
+                    slow[j] = differ & !roots;
+                    lo[j] = pa[j] < pc[j] ? pa[j] : pc[j];
+                    hi[j] = pa[j] < pc[j] ? pc[j] : pa[j];
+                    // halving: an endpoint whose parent is not a root moves up (it is not a root itself then)
+                    if (utwo[j] & (ga[j] != pa[j])) uf.set(ua[j], ga[j]);
+                    if (utwo[j] & (gc[j] != pc[j])) uf.set(uc[j], gc[j]);
+                    if (link[j]) uf.set(hi[j], lo[j]);
+                }
+                SSE_WAVE_FENCE();
+                uint32_t chk[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) chk[j] = uf.get(link[j] ? hi[j] : 0u);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const bool redo = slow[j] | (link[j] & (chk[j] != lo[j]));
+                    if (__any(redo)) { if (redo) uf_union_wave(uf, pa[j], pc[j]); }
+                }
             }
         }
     }
@@ -1113,10 +1157,11 @@ namespace sse {
 // the diagonal pass alone.  The diagonal pass needs half the registers and a quarter of the LDS of the cluster
 // pass, so as its own kernel it runs at twice the occupancy (4 waves per SIMD for W <= 4); the host then issues
 // two launches per timestep (isingmc_hip.hip, run()).  n, cutoff, epoch, chunk counters travel through HBM.
+// SSE_PASSES_OFFDIAG is the second of those launches with the diagonal and RVB code left out (fewer live scalars).
 #ifndef SSE_MIN_WAVES_PER_SIMD
 #define SSE_MIN_WAVES_PER_SIMD 1
 #endif
-enum { SSE_PASSES_ALL = 0, SSE_PASSES_DIAG = 1 };
+enum { SSE_PASSES_ALL = 0, SSE_PASSES_DIAG = 1, SSE_PASSES_OFFDIAG = 2 }; // OFFDIAG: directed loop + cluster + free spins + sampling
 template <int W, int PASSES>
 constexpr int sse_waves_per_simd() {
     if (PASSES == SSE_PASSES_DIAG) return W <= 4 ? 4 : (W <= 8 ? 2 : 1);
@@ -1141,6 +1186,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
     uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0;
     for (uint64_t step = 0; step < A.nsteps; ++step) {
         if (err) break;
+        if constexpr (PASSES != SSE_PASSES_OFFDIAG)
         if (A.domask & SSE_DO_DIAG) {
             const Rng rng = make_rng(B, r, epoch);
             if (A.domask & SSE_DO_HEATBATH) diagonal_pass<W, K, CL, true>(B, L, r, rng, beta, M, n, ntrans, gr);
@@ -1152,7 +1198,8 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
                 if (want > M) { if (want > B.cap) { err = 1u; break; } M = want; }
             }
         }
-        if constexpr (PASSES == SSE_PASSES_ALL) {
+        if constexpr (PASSES != SSE_PASSES_DIAG) {
+        if constexpr (PASSES == SSE_PASSES_ALL)
         if (A.domask & SSE_DO_RVB) { // qmc_ising.rs:705-752
             const uint32_t updates = A.rvb_updates ? A.rvb_updates : (B.N + 1u) / 2u;
             last_out = rvb_pass<W, CL>(B, L, r, epoch, M, updates, gr, err);
@@ -1194,10 +1241,10 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
             a0 += (uint64_t)n; a1 += 1; a2 += (uint64_t)(mag < 0 ? -mag : mag); a3 += (uint64_t)(mag * mag); a6 += (uint64_t)ntrans;
             __syncthreads();
         }
-        } // PASSES == SSE_PASSES_ALL
+        } // PASSES != SSE_PASSES_DIAG
     }
     __syncthreads();
-    if constexpr (PASSES == SSE_PASSES_ALL)
+    if constexpr (PASSES != SSE_PASSES_DIAG)
         for (uint32_t i = tid; i < B.nwords; i += NT) B.state[(size_t)r * B.nwords + i] = LDSW(L.o_state, i);
     for (uint32_t i = tid; i < 2 * SSE_MAX_CHUNKS; i += NT) B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i] = LDSW(L.o_chn, i);
     if (tid == 0) {
@@ -1233,6 +1280,10 @@ hipError_t launch_k(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
     if (c.passes == SSE_PASSES_DIAG) {
         if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_DIAG>(c, B, A);
         return launch_one<W, K, CL, 0, SSE_PASSES_DIAG>(c, B, A);
+    }
+    if (c.passes == SSE_PASSES_OFFDIAG) {
+        if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_OFFDIAG>(c, B, A);
+        return launch_one<W, K, CL, 0, SSE_PASSES_OFFDIAG>(c, B, A);
     }
     if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_ALL>(c, B, A); // data-preparation symbol: default geometry only
     return launch_one<W, K, CL, 0, SSE_PASSES_ALL>(c, B, A);
