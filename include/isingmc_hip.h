@@ -67,6 +67,9 @@ typedef struct isingmc_config {
     uint32_t flags;             /* ISINGMC_CFG_* */
     uint32_t lds_uf_ids_limit;  /* 0 = as many cluster-segment ids as fit in LDS; smaller values force the HBM
                                    union-find path earlier (testing) */
+    uint32_t waves_offdiag;     /* wave64s per replica for launches without a diagonal pass (directed loop, cluster,
+                                 * free spins): 0 = same as waves_per_replica when that is given, otherwise decided
+                                 * per launch (16 while the scan tables and the union-find fit in LDS); 1, 4, 6, 8, 16 */
 } isingmc_config;
 
 /* QmcIsingGraph::new_with_rng (qmc_ising.rs:131-148) + OpContainerConstructor::new_with_bonds
@@ -154,7 +157,8 @@ int isingmc_debug_phase_ticks(isingmc_batch *b, uint64_t *out, int reset);
 int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
 /* build/launch configuration actually in use: out[0]=waves per replica, out[1]=dynamic LDS bytes,
  * out[2]=union-find ids that fit in LDS, out[3]=state words per replica, out[4]=slots per lane,
- * out[5]=1 if the edge table is staged in LDS, out[6]=1 if timesteps are issued as two launches (diagonal, rest),
+ * out[5]=1 if the edge table is staged in LDS, out[6]=bit 0: timesteps are issued as two launches (diagonal, rest); bits 8-15: waves per replica of the
+ * most recent off-diagonal launch,
  * out[7]=dynamic LDS bytes of the diagonal-pass launch */
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]);
 

@@ -37,7 +37,7 @@ class _Config(C.Structure):
                 ("cutoff0", C.c_uint32), ("seed", C.c_uint64), ("replica_offset", C.c_uint32),
                 ("device", C.c_int32), ("init_state", C.POINTER(C.c_uint8)),
                 ("waves_per_replica", C.c_uint32), ("slots_per_lane", C.c_uint32), ("flags", C.c_uint32),
-                ("lds_uf_ids_limit", C.c_uint32)]
+                ("lds_uf_ids_limit", C.c_uint32), ("waves_offdiag", C.c_uint32)]
 
 
 # every symbol include/isingmc_hip.h declares: name -> (restype, argtypes)
@@ -126,7 +126,7 @@ class QmcIsingGraph:
 
     def __init__(self, edges, transverse, longitudinal, cutoff, seed, state=None, nreplicas=1,
                  capacity=None, replica_offset=0, device=-1, waves_per_replica=0, slots_per_lane=0,
-                 cfg_flags=0, lds_uf_ids_limit=0):
+                 cfg_flags=0, lds_uf_ids_limit=0, waves_offdiag=0):
         lib = load_library()
         self._lib = lib
         self._h = None
@@ -154,7 +154,7 @@ class QmcIsingGraph:
                       replica_offset=int(replica_offset), device=int(device),
                       init_state=_ptr(init, C.c_uint8) if init is not None else None,
                       waves_per_replica=int(waves_per_replica), slots_per_lane=int(slots_per_lane),
-                      flags=int(cfg_flags), lds_uf_ids_limit=int(lds_uf_ids_limit))
+                      flags=int(cfg_flags), lds_uf_ids_limit=int(lds_uf_ids_limit), waves_offdiag=int(waves_offdiag))
         h = C.c_void_p()
         rc = lib.isingmc_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -341,7 +341,7 @@ class QmcIsingGraph:
         out = (C.c_uint32 * 8)()
         self._check(self._lib.isingmc_get_launch_info(self._h, out))
         return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3],
-                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6]),
+                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), waves_offdiag=(out[6] >> 8) & 0xFF,
                     lds_bytes_diagonal=out[7])
 
     def debug_phase_ticks(self, reset=True):

@@ -17,6 +17,8 @@ static thread_local std::string g_create_error;
 struct isingmc_batch {
     DevBatch dev{};
     uint32_t W = 8, K = 4, CL = 0;
+    uint32_t W_off = 0;                 // waves per replica of the off-diagonal launches; 0 = decide per launch (16 when its tables fit in LDS)
+    uint32_t last_W_off = 0;
     uint64_t steps_per_launch = 0;
     uint32_t acc_rows = 0;
     uint32_t rvb_updates = 0;
@@ -132,17 +134,28 @@ static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t 
 // ids fit; its capacity follows the largest transverse-op count seen so far (+ headroom), so that the footprint
 // stays small enough for two workgroups per CU whenever the model allows it.  Replicas that outgrow it use the HBM
 // union-find for that sweep and the host enlarges the table before the next launch.
-static void size_lds(isingmc_batch *b) {
-    DevBatch &D = b->dev;
-    const size_t ids_max = (size_t)b->W * D.N + D.cap;
-    size_t ids = (size_t)b->W * D.N + b->max_ntrans + b->max_ntrans / 16 + 384;
+struct LdsPlan { uint32_t W, ufcap; size_t lds_bytes; bool all_ids_fit; };
+static LdsPlan plan_lds(const isingmc_batch *b, uint32_t W) {
+    const DevBatch &D = b->dev;
+    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, b->CL ? D.E : 0u);
+    const size_t ids_max = (size_t)W * D.N + D.cap;
+    const size_t want = (size_t)W * D.N + b->max_ntrans + b->max_ntrans / 16 + 384;
+    size_t ids = want;
     if (b->uf_ids_limit) ids = b->uf_ids_limit;
     if (ids > 65535) ids = 65535;
     if (ids > ids_max) ids = ids_max;
     auto words = [&](size_t n) { return (n + 1) / 2 + (D.has_long ? 2 * ((n + 31) / 32) : 0); };
-    while (ids > 0 && b->lds_fixed_words_ + words(ids) > b->lds_total_words) ids -= (ids > 64 ? 64 : ids);
-    D.lds_ufcap = (uint32_t)ids;
-    b->lds_bytes = (4 * (b->lds_fixed_words_ + words(ids)) + 7) & ~(size_t)7;
+    while (ids > 0 && fixed + words(ids) > b->lds_total_words) ids -= (ids > 64 ? 64 : ids);
+    LdsPlan p;
+    p.W = W; p.ufcap = (uint32_t)ids;
+    p.lds_bytes = (4 * (fixed + words(ids)) + 7) & ~(size_t)7;
+    p.all_ids_fit = fixed + 64 <= b->lds_total_words && ids >= (want < ids_max ? want : ids_max) && !b->uf_ids_limit;
+    return p;
+}
+static void size_lds(isingmc_batch *b) {
+    const LdsPlan p = plan_lds(b, b->W);
+    b->dev.lds_ufcap = p.ufcap;
+    b->lds_bytes = p.lds_bytes;
 }
 
 static int check_errors(isingmc_batch *b) {
@@ -201,16 +214,17 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     size_lds(b);
     lc.lds_bytes = ((domask & SSE_DO_RVB) && b->lds_bytes_rvb > b->lds_bytes) ? b->lds_bytes_rvb : b->lds_bytes;
     b->dev.lds_words = (uint32_t)(lc.lds_bytes / 4);
-    auto launch = [&](const LaunchCfg &c, const SweepArgs &a) -> hipError_t {
-        switch (b->W) {
-        case 1: return launch_sweep_w1(c, b->dev, a);
-        case 4: return launch_sweep_w4(c, b->dev, a);
-        case 6: return launch_sweep_w6(c, b->dev, a);
-        case 8: return launch_sweep_w8(c, b->dev, a);
-        case 16: return launch_sweep_w16(c, b->dev, a);
+    auto launch_dev = [&](const LaunchCfg &c, const DevBatch &dev, const SweepArgs &a) -> hipError_t {
+        switch (c.W) {
+        case 1: return launch_sweep_w1(c, dev, a);
+        case 4: return launch_sweep_w4(c, dev, a);
+        case 6: return launch_sweep_w6(c, dev, a);
+        case 8: return launch_sweep_w8(c, dev, a);
+        case 16: return launch_sweep_w16(c, dev, a);
         default: return hipErrorInvalidValue;
         }
     };
+    auto launch = [&](const LaunchCfg &c, const SweepArgs &a) -> hipError_t { return launch_dev(c, b->dev, a); };
     auto fail_launch = [&](hipError_t e) { b->err = std::string("sweep launch: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; };
     uint32_t launches = 0;
     b->pass_ms[0] = b->pass_ms[1] = 0.f;
@@ -219,14 +233,28 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     const bool split = !b->fused_launch && (A.domask & SSE_DO_DIAG);
     size_t timed_steps = 0; // split path: steps whose launches carry events
     // launches without a diagonal or RVB pass use the kernel that leaves that code out
-    if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB)) || (split && !(A.domask & SSE_DO_RVB))) lc.passes = SSE_PASSES_OFFDIAG;
+    DevBatch dev_off = b->dev;
+    if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB)) || (split && !(A.domask & SSE_DO_RVB))) {
+        lc.passes = SSE_PASSES_OFFDIAG;
+        // The off-diagonal kernel is latency-bound and small in registers: more waves per replica help as long as
+        // the per-wave scan tables and the union-find of W*N + (transverse ops) ids still fit in LDS.
+        uint32_t Wo = b->W_off ? b->W_off : b->W;
+        if (!b->W_off && b->W < 16) {
+            const LdsPlan p16 = plan_lds(b, 16);
+            if (p16.all_ids_fit) Wo = 16;
+        }
+        const LdsPlan po = plan_lds(b, Wo);
+        lc.W = Wo; lc.lds_bytes = po.lds_bytes;
+        dev_off.lds_ufcap = po.ufcap; dev_off.lds_words = (uint32_t)(po.lds_bytes / 4);
+        b->last_W_off = Wo;
+    }
     HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
     if (!split) {
         const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;
         for (uint64_t done = 0; done < nsteps; done += per) {
             A.step0 = done;
             A.nsteps = (nsteps - done < per) ? nsteps - done : per;
-            const hipError_t e = launch(lc, A);
+            const hipError_t e = launch_dev(lc, lc.passes == SSE_PASSES_OFFDIAG ? dev_off : b->dev, A);
             if (e != hipSuccess) return fail_launch(e);
             launches++;
         }
@@ -236,6 +264,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         // union-find LDS nor the registers of the cluster scan), then everything else.  Same Philox epochs, same
         // results as the fused launch; n / cutoff / chunk counters go through HBM in between (a few KB per replica).
         LaunchCfg ld = lc;
+        ld.W = b->W;
         ld.passes = SSE_PASSES_DIAG;
         ld.lds_bytes = (4 * b->lds_fixed_words_ + 7) & ~(size_t)7;
         const uint32_t rest = A.domask & ~diag_bits;
@@ -255,7 +284,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             if (rest || sample) {
                 SweepArgs a2 = A;
                 a2.domask = rest; a2.nsteps = 1; a2.step0 = done;
-                e = launch(lc, a2);
+                e = launch_dev(lc, lc.passes == SSE_PASSES_OFFDIAG ? dev_off : b->dev, a2);
                 if (e != hipSuccess) return fail_launch(e);
                 launches++; b->pass_launches[1]++;
             }
@@ -360,13 +389,19 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : (W == 6 ? 4 : W >> 1);
     const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges);
     if (fixed + 64 > total_words) { b->err = "model too large: per-variable scan tables do not fit in LDS"; return fail(ISINGMC_ENOTIMPL); }
-    const size_t ids_max = (size_t)W * D.N + D.cap;
+    // off-diagonal launches may use their own wave count (see run()): explicit, or decided per launch (then up to 16)
+    uint32_t W_off = cfg->waves_offdiag;
+    if (W_off != 0 && W_off != 1 && W_off != 4 && W_off != 6 && W_off != 8 && W_off != 16) { b->err = "waves_offdiag must be 0, 1, 4, 6, 8 or 16"; return fail(ISINGMC_EINVAL); }
+    if (!W_off && cfg->waves_per_replica) W_off = W; // an explicit waves_per_replica pins both kinds of launch
+    if (W_off && lds_fixed_words(W_off, D.N, D.nwords, ledges) + 64 > total_words) W_off = W;
+    const uint32_t Wmax = W_off ? (W_off > W ? W_off : W) : (W > 16 ? W : 16);
+    const size_t ids_max = (size_t)Wmax * D.N + D.cap;
     // chunk grid for the per-chunk counters: <= SSE_MAX_CHUNKS chunks of CH slots, CH a multiple of 256
     D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
     D.nchunks = (D.cap + D.CH - 1) / D.CH;
-    b->W = W; b->K = K; b->CL = CL ? 1u : 0u;
+    b->W = W; b->K = K; b->CL = CL ? 1u : 0u; b->W_off = W_off;
     { // row stride: whole tiles, plus room for the (unused) prefetch of a cluster-scan wave whose chunk range is empty
-        const size_t tile = (size_t)W * 64 * K;
+        const size_t tile = (Wmax % W == 0 ? (size_t)Wmax : (size_t)Wmax * W) * 64 * K; // whole tiles of either launch geometry
         const size_t need1 = ((size_t)D.cap + tile - 1) / tile * tile;
         const size_t need2 = ((size_t)D.cap + D.CH - 1) / D.CH * D.CH + 256;
         const size_t need = need1 > need2 ? need1 : need2;
@@ -740,7 +775,7 @@ int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->CL; out[6] = b->fused_launch ? 0u : 1u; out[7] = (uint32_t)((4 * b->lds_fixed_words_ + 7) & ~(size_t)7);
+    out[4] = b->K; out[5] = b->CL; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8); out[7] = (uint32_t)((4 * b->lds_fixed_words_ + 7) & ~(size_t)7);
     return ISINGMC_OK;
 }
 

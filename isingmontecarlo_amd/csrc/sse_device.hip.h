@@ -93,6 +93,14 @@ struct SweepArgs {
     uint32_t *out_u32; // optional per-replica output (n_clusters / loop length / RVB successes) of the LAST step
 };
 
+// scalar add that the optimiser may not hoist or merge: the ten round keys are wave-uniform and loop-invariant,
+// and hoisted out of the sweep loops they would occupy 20 scalar registers for the whole kernel (they were being
+// spilled to vector lanes and read back with v_readlane on every use); one s_add per key and call is cheaper
+__device__ __forceinline__ uint32_t philox_bump(uint32_t k, uint32_t w) {
+    uint32_t r;
+    asm volatile("s_add_u32 %0, %1, %2" : "=s"(r) : "s"(k), "s"(w) : "scc");
+    return r;
+}
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1) {
 #pragma unroll
@@ -101,8 +109,7 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
         uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
+        if (i < 9) { k0 = philox_bump(k0, 0x9E3779B9u); k1 = philox_bump(k1, 0xBB67AE85u); }
     }
     return make_uint4(c0, c1, c2, c3);
 }
