@@ -115,7 +115,7 @@ def main():
     for _ in range(0, args.equilibrate, 10):  # in chunks: the LDS union-find capacity adapts between launches
         g.run(min(10, args.equilibrate), beta, flags=(flags & ~im.FLAG_RVB) | im.FLAG_PREP)
     # Two kernel launches per sweep (isingmc_hip.hip run()): the diagonal pass (sse::sweep_kernel<..,PASSES=1>) and
-    # everything else (sse::sweep_kernel<..,PASSES=0>: directed loop + cluster + free spins).  A "launch" in the
+    # everything else (sse::sweep_kernel<..,PASSES=2>: directed loop + cluster + free spins).  A "launch" in the
     # roofline object is one launch of the dominant kernel = its pass over all R replicas of this rank.
     if args.warmup:
         g.run(args.warmup, beta, flags=flags)
@@ -157,7 +157,7 @@ def main():
             b_rest += 8.0  # find_constants reads the op-string twice (count + fill); window traffic not counted
         kernels = []
         for name, bps, ms, nl in (("sse::sweep_kernel<W,K,CL,0,PASSES=1> (diagonal pass)", BYTES_PER_SLOT_DIAG, ms_diag, l_diag),
-                                  ("sse::sweep_kernel<W,K,CL,0,PASSES=0> (directed loop + cluster + free spins)", b_rest, ms_rest, l_rest)):
+                                  ("sse::sweep_kernel<W,K,CL,0,PASSES=2> (directed loop + cluster + free spins)", b_rest, ms_rest, l_rest)):
             if nl == 0:
                 continue
             per_launch_bytes = bps * slots / args.steps
@@ -166,6 +166,15 @@ def main():
                             "algorithmic_bytes_per_launch": per_launch_bytes,
                             "achieved_GBps": per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0})
         dom = max(kernels, key=lambda k: k["kernel_ms_per_launch"] * k["launches"])
+        traffic = args.traffic_bytes
+        if traffic is None and L == 32 and R == 1024 and beta == 16.0 and not args.rvb and not args.no_loop:
+            # HBM bytes per launch of the dominant kernel from the PMC passes of this same workload (cannot be
+            # collected inside this process: rocprofv3 counters need their own runs), see profiles/README.md
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                    traffic = float(json.load(f)["PASSES=2" if "PASSES=0" in dom["kernel"] or "PASSES=2" in dom["kernel"] else "PASSES=1"])
+            except (OSError, KeyError, ValueError):
+                traffic = None
         achieved = dom["achieved_GBps"]
         bytes_per_sweep = sum(k["algorithmic_bytes_per_launch"] for k in kernels)
         sweep_ms = kernel_ms / args.steps
@@ -193,7 +202,7 @@ def main():
                        "energy_per_site": float(energy.mean() / (L * L)),
                        "energy_per_site_sem": float(energy.std(ddof=1) / np.sqrt(R) / (L * L)) if R > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dom["kernel"], "kernel_ms_per_launch": dom["kernel_ms_per_launch"], "launches": dom["launches"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "bytes_per_slot": dom["bytes_per_slot"],
                          "all_kernels": kernels,
