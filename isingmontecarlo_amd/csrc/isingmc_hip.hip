@@ -229,12 +229,16 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     uint32_t launches = 0;
     b->pass_ms[0] = b->pass_ms[1] = 0.f;
     b->pass_launches[0] = b->pass_launches[1] = 0;
-    const uint32_t diag_bits = SSE_DO_DIAG | SSE_DO_HEATBATH | SSE_DO_GROW;
+    // passes of the first ("diagonal") launch of a split timestep: the diagonal pass and, unless an RVB sweep has to
+    // come in between, the directed loop (one sequential walk: it gains nothing from the wider off-diagonal geometry)
+    const uint32_t diag_bits = SSE_DO_DIAG | SSE_DO_HEATBATH | SSE_DO_GROW | ((A.domask & SSE_DO_RVB) ? 0u : SSE_DO_LOOP);
     const bool split = !b->fused_launch && (A.domask & SSE_DO_DIAG);
     size_t timed_steps = 0; // split path: steps whose launches carry events
     // launches without a diagonal or RVB pass use the kernel that leaves that code out
     DevBatch dev_off = b->dev;
-    if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB)) || (split && !(A.domask & SSE_DO_RVB))) {
+    const bool loop_only = (A.domask & (SSE_DO_DIAG | SSE_DO_RVB | SSE_DO_CLUSTER | SSE_DO_FREE)) == 0 && (A.domask & SSE_DO_LOOP);
+    if (loop_only) lc.passes = SSE_PASSES_DIAG; // a lone directed loop uses the small launch geometry too
+    else if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB | SSE_DO_LOOP)) || (split && !(A.domask & SSE_DO_RVB))) {
         lc.passes = SSE_PASSES_OFFDIAG;
         // The off-diagonal kernel is latency-bound and small in registers: more waves per replica help as long as
         // the per-wave scan tables and the union-find of W*N + (transverse ops) ids still fit in LDS.

@@ -1168,7 +1168,7 @@ namespace sse {
 #ifndef SSE_MIN_WAVES_PER_SIMD
 #define SSE_MIN_WAVES_PER_SIMD 1
 #endif
-enum { SSE_PASSES_ALL = 0, SSE_PASSES_DIAG = 1, SSE_PASSES_OFFDIAG = 2 }; // OFFDIAG: directed loop + cluster + free spins + sampling
+enum { SSE_PASSES_ALL = 0, SSE_PASSES_DIAG = 1, SSE_PASSES_OFFDIAG = 2 }; // DIAG: diagonal pass + directed loop; OFFDIAG: cluster + free spins + sampling
 template <int W, int PASSES>
 constexpr int sse_waves_per_simd() {
     if (PASSES == SSE_PASSES_DIAG) return W <= 4 ? 4 : (W <= 8 ? 2 : 1);
@@ -1205,7 +1205,6 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
                 if (want > M) { if (want > B.cap) { err = 1u; break; } M = want; }
             }
         }
-        if constexpr (PASSES != SSE_PASSES_DIAG) {
         if constexpr (PASSES == SSE_PASSES_ALL)
         if (A.domask & SSE_DO_RVB) { // qmc_ising.rs:705-752
             const uint32_t updates = A.rvb_updates ? A.rvb_updates : (B.N + 1u) / 2u;
@@ -1214,6 +1213,8 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
             a4 += updates;
             if (err) break;
         }
+        // the directed loop is one sequential walk: it runs in the small geometry of the diagonal launch
+        if constexpr (PASSES != SSE_PASSES_OFFDIAG)
         if (A.domask & SSE_DO_LOOP) {
             const Rng rng = make_rng(B, r, epoch);
             last_out = loop_pass<W, CL>(B, L, r, rng, M, n, gr, err);
@@ -1221,6 +1222,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
             a4 += last_out;
             if (err) break;
         }
+        if constexpr (PASSES != SSE_PASSES_DIAG) {
         if (A.domask & SSE_DO_CLUSTER) {
             const Rng rng = make_rng(B, r, epoch);
             const uint32_t S_ids = (uint32_t)W * B.N + (uint32_t)ntrans;
@@ -1251,7 +1253,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         } // PASSES != SSE_PASSES_DIAG
     }
     __syncthreads();
-    if constexpr (PASSES != SSE_PASSES_DIAG)
+    // (the directed loop of the diagonal launch can flip p=0 spins too)
         for (uint32_t i = tid; i < B.nwords; i += NT) B.state[(size_t)r * B.nwords + i] = LDSW(L.o_state, i);
     for (uint32_t i = tid; i < 2 * SSE_MAX_CHUNKS; i += NT) B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i] = LDSW(L.o_chn, i);
     if (tid == 0) {
