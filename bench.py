@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--rvb", action="store_true", help="configs[2]: QmcIsingGraph::timestep with RVB sweeps (no directed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--pmj3d", type=int, default=0, metavar="L",
+                    help="secondary workload (configs[4] geometry): L^3 periodic cubic lattice, J=+-1 i.i.d. per replica, "
+                         "Gamma=1, h=0.1, one disorder realisation per replica; use with --beta 4 --replicas 512")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run (profiles/README.md)")
     args = ap.parse_args()
@@ -108,9 +111,22 @@ def main():
     edges = lattice_edges(L)
     n_est = beta * (3 * L * L + 2.2 * L * L)
     cap = 1 << int(np.ceil(np.log2(2.0 * n_est + 4 * L * L)))
-    g = im.QmcIsingGraph(edges, 1.0, 0.0, L * L, args.seed, nreplicas=R, capacity=cap,
-                         replica_offset=rank * R, device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k,
-                         cfg_flags=im.CFG_NO_LDS_TABLES if args.no_lds_tables else 0)
+    if args.pmj3d:
+        import _lattices as lat3
+        L = args.pmj3d
+        edges = lat3.cubic_periodic(L)
+        nsite = L ** 3
+        rngJ = np.random.default_rng(args.seed + 7919 * rank)
+        couplings = rngJ.choice([-1.0, 1.0], size=(R, len(edges)))
+        n_est = beta * (len(edges) * 1.3 + nsite * 1.2)
+        cap = 1 << int(np.ceil(np.log2(2.0 * n_est + 4 * nsite)))
+        flags &= ~im.FLAG_LOOP
+        g = im.QmcIsingGraph(edges, 1.0, 0.1, nsite, args.seed, nreplicas=R, capacity=cap, replica_offset=rank * R,
+                             device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k, couplings=couplings)
+    else:
+        g = im.QmcIsingGraph(edges, 1.0, 0.0, L * L, args.seed, nreplicas=R, capacity=cap,
+                             replica_offset=rank * R, device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k,
+                             cfg_flags=im.CFG_NO_LDS_TABLES if args.no_lds_tables else 0)
     # data preparation: equilibrate (cutoff growth + thermalisation), untimed.  FLAG_PREP runs the identical
     # kernel under its "data preparation" symbol so that rocprofv3 --stats averages only the measured launches.
     for _ in range(0, args.equilibrate, 10):  # in chunks: the LDS union-find capacity adapts between launches
@@ -168,7 +184,7 @@ def main():
                             "achieved_GBps": per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0})
         dom = max(kernels, key=lambda k: k["kernel_ms_per_launch"] * k["launches"])
         traffic = args.traffic_bytes
-        if traffic is None and L == 32 and R == 1024 and beta == 16.0 and not args.rvb and not args.no_loop:
+        if traffic is None and L == 32 and R == 1024 and beta == 16.0 and not args.rvb and not args.no_loop and not args.pmj3d:
             # HBM bytes per launch of the dominant kernel from the PMC passes of this same workload (cannot be
             # collected inside this process: rocprofv3 counters need their own runs), see profiles/README.md
             try:
@@ -179,7 +195,8 @@ def main():
         achieved = dom["achieved_GBps"]
         bytes_per_sweep = sum(k["algorithmic_bytes_per_launch"] for k in kernels)
         sweep_ms = kernel_ms / args.steps
-        energy = -(acc[:, 0] / np.maximum(acc[:, 1], 1)) / beta + g.get_offset()
+        energy = -(acc[:, 0] / np.maximum(acc[:, 1], 1)) / beta + g.get_offsets()
+        nsites = (args.pmj3d ** 3) if args.pmj3d else L * L
         out = {
             "metric": "spin-op updates/sec (whole node), 32x32 TFIM, 1024 replicas per GPU",
             "value": updates / dt,
@@ -193,15 +210,17 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 op words, f64 acceptance arithmetic",
             "data": "synthetic (op-strings equilibrated on device from random spins, Philox seed %d)" % args.seed,
-            "config": {"workload": f"configs[{2 if args.rvb else 1}]: {L}x{L} periodic TFIM J=-1 Gamma=1 h=0 beta={beta}, {R} replicas/GPU, "
-                                   f"{'QmcIsingGraph::timestep = diagonal + RVB sweep + ' if args.rvb else 'Qmc::timestep = diagonal + ' + ('directed loop + ' if not args.no_loop else '')}cluster + free spins",
-                       "replicas_per_gpu": R, "lattice": f"{L}x{L}", "beta": beta,
+            "config": {"workload": (f"configs[4] geometry at reduced size: {L}^3 periodic cubic +-J (one disorder realisation per replica) Gamma=1 h=0.1 beta={beta}, "
+                                    f"{R} replicas/GPU, QmcIsingGraph::timestep = diagonal + cluster + free spins") if args.pmj3d else
+                                   (f"configs[{2 if args.rvb else 1}]: {L}x{L} periodic TFIM J=-1 Gamma=1 h=0 beta={beta}, {R} replicas/GPU, "
+                                    f"{'QmcIsingGraph::timestep = diagonal + RVB sweep + ' if args.rvb else 'Qmc::timestep = diagonal + ' + ('directed loop + ' if not args.no_loop else '')}cluster + free spins"),
+                       "replicas_per_gpu": R, "lattice": f"{L}^3" if args.pmj3d else f"{L}x{L}", "beta": beta,
                        "mean_cutoff_M": mean_M, "mean_n": mean_n, "sweeps_per_s": args.steps / dt,
                        "waves_per_replica": g.launch_info()["waves_per_replica"],
                        "slots_per_lane": g.launch_info()["slots_per_lane"],
                        "lds_bytes_per_workgroup": g.launch_info()["lds_bytes"],
-                       "energy_per_site": float(energy.mean() / (L * L)),
-                       "energy_per_site_sem": float(energy.std(ddof=1) / np.sqrt(R) / (L * L)) if R > 1 else None},
+                       "energy_per_site": float(energy.mean() / nsites),
+                       "energy_per_site_sem": float(energy.std(ddof=1) / np.sqrt(R) / nsites) if R > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dom["kernel"], "kernel_ms_per_launch": dom["kernel_ms_per_launch"], "launches": dom["launches"],

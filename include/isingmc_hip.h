@@ -42,6 +42,8 @@ extern "C" {
 
 /* isingmc_config.flags */
 #define ISINGMC_CFG_NO_LDS_TABLES 1u /* keep the bond table in HBM even when it would fit in LDS (testing) */
+#define ISINGMC_CFG_PER_REPLICA_J 4u /* `J` holds nreplicas x nedges couplings (row r = replica r): independent disorder
+                                        realisations on one graph.  RVB updates are not available in this mode. */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 
@@ -53,7 +55,7 @@ typedef struct isingmc_config {
     uint32_t nvars;           /* N (reference: max edge index + 1, qmc_ising.rs:92) */
     uint32_t nedges;          /* E */
     const uint32_t *edges;    /* [2E]: a0,b0,a1,b1,...  (Vec<(Edge,f64)>, qmc_ising.rs:81) */
-    const double *J;          /* [E]  couplings, J>0 antiferromagnetic (src/lib.rs:29) */
+    const double *J;          /* [E]  couplings, J>0 antiferromagnetic (src/lib.rs:29); [R][E] with ISINGMC_CFG_PER_REPLICA_J */
     double transverse;        /* Gamma */
     double longitudinal;      /* h */
     uint32_t capacity;        /* op-string slots preallocated per replica (>= cutoff0) */
@@ -107,6 +109,8 @@ int isingmc_get_accumulators(isingmc_batch *b, uint64_t *out);
 int isingmc_reset_accumulators(isingmc_batch *b);
 /* QmcIsingGraph::get_offset (qmc_ising.rs:558) */
 double isingmc_get_offset(const isingmc_batch *b);
+/* the same per replica, out[R] (differs between replicas only with ISINGMC_CFG_PER_REPLICA_J) */
+int isingmc_get_offsets(const isingmc_batch *b, double *out);
 uint32_t isingmc_num_bonds(const isingmc_batch *b);
 
 /* state_ref / clone_state / state_mut (qmc_ising.rs:497-509,797): out/in are [N] bytes 0/1 of replica r;

@@ -13,11 +13,12 @@ import numpy as np
 from . import _build
 
 __all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
-           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH"]
+           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J"]
 
 FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
 FLAG_PREP = 0x10000
 CFG_NO_LDS_TABLES = 1
+CFG_PER_REPLICA_J = 4  # J is [nreplicas][nedges]: one disorder realisation per replica
 CFG_FUSED_LAUNCH = 2  # whole timesteps in one kernel launch (default: diagonal launch + off-diagonal launch)
 ALL = 0xFFFFFFFF
 
@@ -76,6 +77,7 @@ SYMBOLS = {
     "isingmc_synchronize": (C.c_int, [_vp]),
     "isingmc_last_kernel_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
     "isingmc_last_pass_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
+    "isingmc_get_offsets": (C.c_int, [_vp, _P(C.c_double)]),
     "isingmc_get_launch_info": (C.c_int, [_vp, _P(_u32)]),
 }
 
@@ -126,7 +128,9 @@ class QmcIsingGraph:
 
     def __init__(self, edges, transverse, longitudinal, cutoff, seed, state=None, nreplicas=1,
                  capacity=None, replica_offset=0, device=-1, waves_per_replica=0, slots_per_lane=0,
-                 cfg_flags=0, lds_uf_ids_limit=0, waves_offdiag=0):
+                 cfg_flags=0, lds_uf_ids_limit=0, waves_offdiag=0, couplings=None):
+        """`couplings` (float64 [nreplicas][nedges]) gives every replica its own J values on the same graph (disorder
+        realisations, BASELINE configs[4]); the J of `edges` is then ignored."""
         lib = load_library()
         self._lib = lib
         self._h = None
@@ -137,6 +141,11 @@ class QmcIsingGraph:
         self.nvars = int(ed.max()) + 1  # qmc_ising.rs:92
         self.nreplicas = int(nreplicas)
         self.transverse, self.longitudinal = float(transverse), float(longitudinal)
+        if couplings is not None:
+            js = np.ascontiguousarray(np.asarray(couplings, dtype=np.float64))
+            if js.shape != (int(nreplicas), len(ed)):
+                raise IsingMcError(-1, "couplings must have shape [nreplicas][nedges]")
+            cfg_flags = int(cfg_flags) | CFG_PER_REPLICA_J
         self.edges, self.J = ed, js
         if capacity is None:
             capacity = max(int(cutoff), 64)
@@ -148,7 +157,7 @@ class QmcIsingGraph:
             init = np.ascontiguousarray(st)
             if init.shape != (self.nreplicas, self.nvars):
                 raise IsingMcError(-1, "initial state has the wrong shape")
-        cfg = _Config(struct_size=C.sizeof(_Config), nreplicas=self.nreplicas, nvars=self.nvars, nedges=len(js),
+        cfg = _Config(struct_size=C.sizeof(_Config), nreplicas=self.nreplicas, nvars=self.nvars, nedges=len(ed),
                       edges=_ptr(ed, C.c_uint32), J=_ptr(js, C.c_double), transverse=self.transverse,
                       longitudinal=self.longitudinal, capacity=int(capacity), cutoff0=int(cutoff), seed=int(seed),
                       replica_offset=int(replica_offset), device=int(device),
@@ -261,9 +270,15 @@ class QmcIsingGraph:
     def get_offset(self):
         return self._lib.isingmc_get_offset(self._h)
 
+    def get_offsets(self):
+        """Energy offset of every replica (they differ only with per-replica couplings)."""
+        out = np.zeros(self.nreplicas, dtype=np.float64)
+        self._check(self._lib.isingmc_get_offsets(self._h, _ptr(out, C.c_double)))
+        return out
+
     def get_energy_for_average_n(self, average_n, beta):
         """qmc_ising.rs:805-809"""
-        return -(np.asarray(average_n, dtype=np.float64) / beta) + self.get_offset()
+        return -(np.asarray(average_n, dtype=np.float64) / beta) + self.get_offsets()
 
     def num_bonds(self):
         return self._lib.isingmc_num_bonds(self._h)

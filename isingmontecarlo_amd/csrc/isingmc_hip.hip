@@ -35,6 +35,8 @@ struct isingmc_batch {
     float pass_ms[2] = {0.f, 0.f};      // [0] diagonal-only launches, [1] all other launches of the last run
     uint32_t pass_launches[2] = {0, 0};
     double offset = 0.0;
+    std::vector<double> offsets;        // per-replica energy offsets (ISINGMC_CFG_PER_REPLICA_J), else empty
+    bool per_replica_J = false;
     std::vector<BondRec> bonds_host;
     double *d_beta = nullptr;
     uint32_t *d_out = nullptr;
@@ -103,7 +105,7 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
         count++;
         const uint32_t b = sse_op_bond(w);
         if (b >= B.Nb) { good = false; break; }
-        const BondRec rec = B.bonds[b];
+        const BondRec rec = B.bonds[(size_t)r * B.bond_stride + b];
         Bd d;
         d.a = rec.a_info & SSE_VAR_MASK; d.c = rec.c; d.kp = rec.a_info >> SSE_INFO_SHIFT; d.w = rec.w;
         const uint32_t in = sse_op_in(w), out = sse_op_out(w);
@@ -204,6 +206,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         b->err = "beta is required for a diagonal update";
         return ISINGMC_EINVAL;
     }
+    if ((domask & SSE_DO_RVB) && b->per_replica_J) { b->err = "RVB updates with per-replica couplings are not implemented"; return ISINGMC_ENOTIMPL; }
     A.sampling_freq = freq;
     A.domask = domask & 0xFFFFu;
     A.prob = prob;
@@ -346,32 +349,45 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     D.seed_lo = (uint32_t)cfg->seed; D.seed_hi = (uint32_t)(cfg->seed >> 32);
     D.replica_offset = cfg->replica_offset;
 
-    // bond table (qmc_ising.rs:186-205,228-246; weights :863-888; offsets :97-99)
+    // bond table (qmc_ising.rs:186-205,228-246; weights :863-888; offsets :97-99); one per replica when every
+    // replica has its own couplings (disorder realisations, ISINGMC_CFG_PER_REPLICA_J: cfg->J is [R][E])
+    const bool perJ = (cfg->flags & ISINGMC_CFG_PER_REPLICA_J) != 0;
+    const uint32_t nH = perJ ? D.R : 1u;
+    b->per_replica_J = perJ;
     std::vector<BondRec> &tab = b->bonds_host;
-    tab.resize(D.Nb);
-    std::vector<double> cum(D.Nb);
-    double off = 0.0;
-    for (uint32_t e = 0; e < D.E; ++e) {
-        const double J = cfg->J[e];
-        tab[e].a_info = cfg->edges[2 * e] | ((SSE_BOND_TWO_SITE | (J < 0.0 ? SSE_BOND_PREF_BIT : 0u)) << SSE_INFO_SHIFT);
-        tab[e].c = cfg->edges[2 * e + 1];
-        tab[e].w = 2.0 * std::fabs(J);
-        off += std::fabs(J);
-    }
-    for (uint32_t v = 0; v < D.N; ++v) {
-        BondRec &t = tab[D.E + v];
-        t.a_info = v | (SSE_BOND_TRANSVERSE << SSE_INFO_SHIFT); t.c = SSE_NO_VAR; t.w = cfg->transverse;
-    }
-    if (has_long)
-        for (uint32_t v = 0; v < D.N; ++v) {
-            BondRec &t = tab[D.E + D.N + v];
-            t.a_info = v | ((SSE_BOND_LONGITUDINAL | (cfg->longitudinal > 0.0 ? SSE_BOND_PREF_BIT : 0u)) << SSE_INFO_SHIFT);
-            t.c = SSE_NO_VAR; t.w = 2.0 * std::fabs(cfg->longitudinal);
+    tab.resize((size_t)nH * D.Nb);
+    std::vector<double> cum((size_t)nH * D.Nb), wtots(nH);
+    if (perJ) b->offsets.resize(nH);
+    for (uint32_t hI = 0; hI < nH; ++hI) {
+        BondRec *t0 = tab.data() + (size_t)hI * D.Nb;
+        const double *Jh = cfg->J + (size_t)hI * D.E;
+        double off = 0.0;
+        for (uint32_t e = 0; e < D.E; ++e) {
+            const double J = Jh[e];
+            t0[e].a_info = cfg->edges[2 * e] | ((SSE_BOND_TWO_SITE | (J < 0.0 ? SSE_BOND_PREF_BIT : 0u)) << SSE_INFO_SHIFT);
+            t0[e].c = cfg->edges[2 * e + 1];
+            t0[e].w = 2.0 * std::fabs(J);
+            off += std::fabs(J);
         }
-    b->offset = off + (double)D.N * (cfg->transverse + std::fabs(cfg->longitudinal));
-    double c = 0.0;
-    for (uint32_t i = 0; i < D.Nb; ++i) { c = (i == 0) ? tab[0].w : tab[i].w + c; cum[i] = c; }
-    D.wtot = c;
+        for (uint32_t v = 0; v < D.N; ++v) {
+            BondRec &t = t0[D.E + v];
+            t.a_info = v | (SSE_BOND_TRANSVERSE << SSE_INFO_SHIFT); t.c = SSE_NO_VAR; t.w = cfg->transverse;
+        }
+        if (has_long)
+            for (uint32_t v = 0; v < D.N; ++v) {
+                BondRec &t = t0[D.E + D.N + v];
+                t.a_info = v | ((SSE_BOND_LONGITUDINAL | (cfg->longitudinal > 0.0 ? SSE_BOND_PREF_BIT : 0u)) << SSE_INFO_SHIFT);
+                t.c = SSE_NO_VAR; t.w = 2.0 * std::fabs(cfg->longitudinal);
+            }
+        const double offset = off + (double)D.N * (cfg->transverse + std::fabs(cfg->longitudinal));
+        if (hI == 0) b->offset = offset;
+        if (perJ) b->offsets[hI] = offset;
+        double c = 0.0;
+        for (uint32_t i = 0; i < D.Nb; ++i) { c = (i == 0) ? t0[0].w : t0[i].w + c; cum[(size_t)hI * D.Nb + i] = c; }
+        wtots[hI] = c;
+    }
+    D.wtot = wtots[0];
+    D.bond_stride = perJ ? D.Nb : 0u;
 
     // launch geometry: W waves per replica, all of LDS for one workgroup
     int max_lds = 0;
@@ -386,9 +402,10 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     // compact edge table staged in LDS when it is small enough (a|c<<15|pref<<30 needs N <= 32768)
     // uniform |J| lets the kernels keep the two-site weight in a scalar register
     D.uniformJ = 1u; D.wJ = tab[0].w;
-    for (uint32_t e = 1; e < D.E; ++e) if (tab[e].w != tab[0].w) { D.uniformJ = 0u; break; }
+    for (uint32_t hI = 0; hI < nH && D.uniformJ; ++hI)
+        for (uint32_t e = 0; e < D.E; ++e) if (tab[(size_t)hI * D.Nb + e].w != tab[0].w) { D.uniformJ = 0u; break; }
     b->fused_launch = (cfg->flags & ISINGMC_CFG_FUSED_LAUNCH) != 0;
-    const bool CL = D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
+    const bool CL = !perJ && D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
     const uint32_t ledges = CL ? D.E : 0u;
     while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : (W == 6 ? 4 : W >> 1);
     const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges);
@@ -398,7 +415,8 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (W_off != 0 && W_off != 1 && W_off != 4 && W_off != 6 && W_off != 8 && W_off != 16) { b->err = "waves_offdiag must be 0, 1, 4, 6, 8 or 16"; return fail(ISINGMC_EINVAL); }
     if (!W_off && cfg->waves_per_replica) W_off = W; // an explicit waves_per_replica pins both kinds of launch
     if (W_off && lds_fixed_words(W_off, D.N, D.nwords, ledges) + 64 > total_words) W_off = W;
-    const uint32_t Wmax = W_off ? (W_off > W ? W_off : W) : (W > 16 ? W : 16);
+    const bool w16_possible = lds_fixed_words(16, D.N, D.nwords, ledges) + 64 <= total_words;
+    const uint32_t Wmax = W_off ? (W_off > W ? W_off : W) : ((W < 16 && w16_possible) ? 16u : W);
     const size_t ids_max = (size_t)Wmax * D.N + D.cap;
     // chunk grid for the per-chunk counters: <= SSE_MAX_CHUNKS chunks of CH slots, CH a multiple of 256
     D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
@@ -444,9 +462,15 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if ((rc = dalloc(b, &D.segs, (size_t)D.R * D.stride, false))) return fail(rc);
     if ((rc = dalloc(b, &D.dbg, (size_t)D.R * 16))) return fail(rc);
     BondRec *dbonds = nullptr; double *dcum = nullptr;
-    if ((rc = dalloc(b, &dbonds, D.Nb, false))) return fail(rc);
-    if ((rc = dalloc(b, &dcum, D.Nb, false))) return fail(rc);
+    if ((rc = dalloc(b, &dbonds, (size_t)nH * D.Nb, false))) return fail(rc);
+    if ((rc = dalloc(b, &dcum, (size_t)nH * D.Nb, false))) return fail(rc);
     D.bonds = dbonds; D.cumw = dcum;
+    if (perJ) {
+        double *dwt = nullptr;
+        if ((rc = dalloc(b, &dwt, nH, false))) return fail(rc);
+        if (hipMemcpy(dwt, wtots.data(), sizeof(double) * nH, hipMemcpyHostToDevice) != hipSuccess) { b->err = "weight upload failed"; return fail(ISINGMC_ENODEVICE); }
+        D.wtot_r = dwt;
+    }
     {
         std::vector<double> ew(D.E);
         std::vector<uint32_t> ce(D.E, 0u);
@@ -484,8 +508,8 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if ((rc = dalloc(b, &b->d_out, D.R))) return fail(rc);
     if ((rc = dalloc(b, &b->d_vstate, (size_t)D.R * D.nwords))) return fail(rc);
     if ((rc = dalloc(b, &b->d_ok, D.R))) return fail(rc);
-    if (hipMemcpy(dbonds, tab.data(), sizeof(BondRec) * D.Nb, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dcum, cum.data(), sizeof(double) * D.Nb, hipMemcpyHostToDevice) != hipSuccess) { b->err = "table upload failed"; return fail(ISINGMC_ENODEVICE); }
+    if (hipMemcpy(dbonds, tab.data(), sizeof(BondRec) * (size_t)nH * D.Nb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dcum, cum.data(), sizeof(double) * (size_t)nH * D.Nb, hipMemcpyHostToDevice) != hipSuccess) { b->err = "table upload failed"; return fail(ISINGMC_ENODEVICE); }
     std::vector<uint32_t> cut(D.R, cfg->cutoff0);
     if (hipMemcpy(D.cutoff, cut.data(), sizeof(uint32_t) * D.R, hipMemcpyHostToDevice) != hipSuccess) { b->err = "cutoff upload failed"; return fail(ISINGMC_ENODEVICE); }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { b->err = "hipEventCreate failed"; return fail(ISINGMC_ENODEVICE); }
@@ -635,6 +659,11 @@ int isingmc_pt_decide(uint64_t seed, uint64_t step, uint32_t nchains, uint32_t n
     return ISINGMC_OK;
 }
 double isingmc_get_offset(const isingmc_batch *b) { return b ? b->offset : 0.0; }
+int isingmc_get_offsets(const isingmc_batch *b, double *out) {
+    if (!b || !out) return ISINGMC_EINVAL;
+    for (uint32_t r = 0; r < b->dev.R; ++r) out[r] = b->per_replica_J ? b->offsets[r] : b->offset;
+    return ISINGMC_OK;
+}
 uint32_t isingmc_num_bonds(const isingmc_batch *b) { return b ? b->dev.Nb : 0u; }
 
 int isingmc_get_state(isingmc_batch *b, uint32_t r, uint8_t *out) {
@@ -693,18 +722,19 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
     if (!b || (!words && nwords) || r >= b->dev.R) { if (b) b->err = "bad arguments to import_ops"; return ISINGMC_EINVAL; }
     if (nwords > b->dev.cap) { b->err = "op-string longer than capacity"; return ISINGMC_ECAPACITY; }
     uint32_t n = 0, ntr = 0;
+    const size_t hoff = b->per_replica_J ? (size_t)r * b->dev.Nb : 0; // this replica's bond table
     std::vector<uint32_t> chunks(2 * SSE_MAX_CHUNKS, 0u);
     for (uint32_t p = 0; p < nwords; ++p) {
         if (!words[p]) continue;
         const uint32_t bond = sse_op_bond(words[p]);
         if (bond >= b->dev.Nb) { b->err = "op refers to a bond outside the model"; return ISINGMC_EINVAL; }
         // Ising bonds: two-site and longitudinal ops have zero off-diagonal weight (qmc_ising.rs:863-888)
-        const uint32_t kind = (b->bonds_host[bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK;
+        const uint32_t kind = (b->bonds_host[hoff + bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK;
         if (kind != SSE_BOND_TRANSVERSE && sse_op_in(words[p]) != sse_op_out(words[p])) { b->err = "off-diagonal op on a diagonal-only bond (zero weight)"; return ISINGMC_EINVAL; }
-        if (b->bonds_host[bond].c == SSE_NO_VAR && ((sse_op_in(words[p]) | sse_op_out(words[p])) & 2u)) { b->err = "single-site op with second-variable bits set"; return ISINGMC_EINVAL; }
+        if (b->bonds_host[hoff + bond].c == SSE_NO_VAR && ((sse_op_in(words[p]) | sse_op_out(words[p])) & 2u)) { b->err = "single-site op with second-variable bits set"; return ISINGMC_EINVAL; }
         n++;
         chunks[p / b->dev.CH]++;
-        if (((b->bonds_host[bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK) == SSE_BOND_TRANSVERSE) { ntr++; chunks[SSE_MAX_CHUNKS + p / b->dev.CH]++; }
+        if (((b->bonds_host[hoff + bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK) == SSE_BOND_TRANSVERSE) { ntr++; chunks[SSE_MAX_CHUNKS + p / b->dev.CH]++; }
     }
     HIP_TRY(b, hipSetDevice(b->device));
     uint32_t *dst = b->dev.ops + (size_t)r * b->dev.stride;

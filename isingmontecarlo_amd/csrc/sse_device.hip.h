@@ -60,6 +60,8 @@ struct DevBatch {
     uint32_t seed_lo, seed_hi, replica_offset;
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
     uint32_t lds_words;   // dynamic LDS words available to the workgroup
+    uint32_t bond_stride; // 0, or Nb when every replica has its own bond table / cumulative weights (per-replica couplings)
+    const double *wtot_r; // [R] per-replica total weight (bond_stride != 0)
     const uint32_t *adj_start, *adj; // [N+1], [2E] bonds_for_var (make_classical_bonds, qmc_ising.rs:421-432)
     uint32_t dbg_flags;   // diagnostic builds only
     unsigned long long *dbg; // [R][16] phase durations in 10-ns ticks (diagnostic builds only, -DSSE_PHASE_TIMING)
@@ -1181,6 +1183,11 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
     L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u, B.has_long);
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
+    if (B.bond_stride) { // per-replica couplings: this replica's tables (B is this workgroup's private copy)
+        B.bonds += (size_t)r * B.bond_stride;
+        B.cumw += (size_t)r * B.bond_stride;
+        B.wtot = B.wtot_r[r];
+    }
     for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_state, i) = B.state[(size_t)r * B.nwords + i];
     if constexpr (CL)
         for (uint32_t i = tid; i < B.E; i += NT) LDSW(L.o_edges, i) = B.edges_compact[i];

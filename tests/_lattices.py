@@ -22,3 +22,16 @@ def two_d_ferro(l):
 
 def split(edges):
     return [list(e) for e, _ in edges], [j for _, j in edges]
+
+
+def cubic_periodic(l):
+    """Periodic simple-cubic lattice, site (x,y,z) -> (z*l + y)*l + x, edges +x, +y, +z per site (J filled in by the caller)."""
+    edges = []
+    for z in range(l):
+        for y in range(l):
+            for x in range(l):
+                a = (z * l + y) * l + x
+                edges.append(((a, (z * l + y) * l + (x + 1) % l), 1.0))
+                edges.append(((a, (z * l + (y + 1) % l) * l + x), 1.0))
+                edges.append(((a, (((z + 1) % l) * l + y) * l + x), 1.0))
+    return edges

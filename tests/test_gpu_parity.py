@@ -251,3 +251,32 @@ def test_large_lattice_64x64_runs_and_matches(oracle):
     assert_same(g, reps, "64x64")
     assert g.verify().all()
     assert 8 * 4096 + 2000 > info["lds_uf_ids"]  # W*N + cuts exceeds the LDS union-find: HBM path exercised
+
+
+@pytest.mark.parametrize("waves,heatbath", [(0, False), (4, True), (1, False)])
+def test_disorder_realisations_cubic_pm_j(oracle, waves, heatbath):
+    """configs[4] in small: +-J random-bond cubic lattice with transverse and longitudinal field, one disorder
+    realisation per replica in ONE batch (ISINGMC_CFG_PER_REPLICA_J); every replica is checked against an oracle
+    replica built on its own couplings."""
+    import isingmontecarlo_amd as im
+    l, R = 4, 6
+    edges = lat.cubic_periodic(l)
+    rng = np.random.default_rng(20260)
+    J = rng.choice([-1.0, 1.0], size=(R, len(edges)))
+    gamma, h, beta, cutoff, cap, seed = 1.0, 0.1, 2.0, 64, 1 << 13, 4096
+    g = im.QmcIsingGraph(edges, gamma, h, cutoff, seed, nreplicas=R, capacity=cap, couplings=J, waves_per_replica=waves)
+    e = [ab for ab, _ in edges]
+    reps = []
+    for r in range(R):
+        m = oracle.Model(g.nvars, e, list(J[r]), gamma, h)
+        reps.append(oracle.Replica(m, cap, cutoff, seed, r, None))
+    flags = im.FLAG_HEATBATH if heatbath else 0
+    g.run(20, beta, flags=flags)
+    oracle.batch_timesteps(reps, 20, [beta] * R, 1, flags)
+    assert_same(g, reps, "cubic +-J")
+    assert g.verify().all()
+    # different realisations, different offsets only through sum |J| (equal here): energies differ through n
+    assert np.allclose(g.get_offsets(), g.get_offset())
+    assert len(set(int(x) for x in g.get_n())) > 1
+    with pytest.raises(im.IsingMcError):
+        g.single_rvb_sweep()
