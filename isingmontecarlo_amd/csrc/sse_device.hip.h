@@ -107,8 +107,9 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
                                                uint32_t k1) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one v_mad_u64_u32 per 32x32->64 product (hi and lo halves together) instead of v_mul_hi + v_mul_lo
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         if (i < 9) { k0 = philox_bump(k0, 0x9E3779B9u); k1 = philox_bump(k1, 0xBB67AE85u); }
@@ -254,6 +255,15 @@ __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 // flip bit 0 of 16-bit element e of the table at word offset off (other waves' tables: 32-bit atomic on the word)
 __device__ __forceinline__ void spin_table_flip(uint32_t off, uint32_t e) { atomicXor(&LDSW(off, e >> 1), 1u << ((e & 1u) * 16u)); }
 
+// A wave-uniform double pinned into vector registers: selects between such values then cost two v_cndmask each,
+// instead of copying scalar halves into vector registers at every use.
+__device__ __forceinline__ double vgpr_copy(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x), vlo, vhi;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"(lo));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"(hi));
+    return __hiloint2double(vhi, vlo);
+}
+
 // slot index of (tile, wave, sub-round j, lane)
 template <int W, int K>
 __device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int lane) {
@@ -284,6 +294,12 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
     const double beta_nb = beta * (double)B.Nb;
     const double hb_bw = beta * B.wtot;
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    // CL mode (uniform |J|): the three bond weights and beta*Nb times them, as vector-register constants
+    double wJv = 0, wGv = 0, wHv = 0, nJv = 0, nGv = 0, nHv = 0;
+    if constexpr (CL) {
+        wJv = vgpr_copy(B.wJ); wGv = vgpr_copy(B.gamma); wHv = vgpr_copy(B.wh);
+        nJv = vgpr_copy(beta_nb * B.wJ); nGv = vgpr_copy(beta_nb * B.gamma); nHv = vgpr_copy(beta_nb * B.wh);
+    }
     // Per-wave spin tables T_w[v] (u16, in the o_cur area the cluster scan uses later): bit 0 = spin of v at the
     // wave's current position; bits 1.. = lane+1 of an off-diagonal op on v inside the sub-round being resolved.
     const uint32_t N = B.N, h_my = (uint32_t)wave * N;
@@ -384,12 +400,31 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             } else {
                 b = occ ? sse_op_bond(wd) : __umulhi(r0, B.Nb);
             }
-            const Bd d = decode_bond<CL, W>(B, L, b);
-            const uint32_t va = d.a, kind = bd_kind(d);
-            const bool two = d.c != SSE_NO_VAR;
-            const uint32_t vc = two ? d.c : va;
+            // bond -> variables, kind, preferred alignment, weight w and beta*Nb*w
+            uint32_t va, vc, pref;
+            bool two, tr;
+            double wbond, nbond;
+            if constexpr (CL) {
+                two = b < B.E;
+                const uint32_t e = LDSW(L.o_edges, two ? b : 0u);
+                const uint32_t s1 = b - B.E;  // wraps far above N for two-site bonds
+                tr = s1 < B.N;
+                va = two ? (e & SSE_CE_VAR_MASK) : (tr ? s1 : s1 - B.N);
+                vc = two ? ((e >> 15) & SSE_CE_VAR_MASK) : va;
+                pref = two ? ((e >> 30) & 1u) : B.hpos;
+                wbond = two ? wJv : (tr ? wGv : wHv);
+                nbond = two ? nJv : (tr ? nGv : nHv);
+            } else {
+                const Bd d = decode_bond<CL, W>(B, L, b);
+                two = d.c != SSE_NO_VAR;
+                tr = bd_kind(d) == SSE_BOND_TRANSVERSE;
+                va = d.a; vc = two ? d.c : va;
+                pref = (d.kp >> 2) & 1u;
+                wbond = d.w;
+                nbond = beta_nb * d.w;
+            }
             evA[j] = va; isevj[j] = isev;
-            trbits |= (kind == SSE_BOND_TRANSVERSE) ? (1u << j) : 0u;
+            trbits |= tr ? (1u << j) : 0u;
             // Spins at this slot = table value, corrected for the off-diagonal ops at EARLIER lanes of this
             // sub-round.  The op word itself carries the spin before (in) and after (out), so the event lanes
             // publish (lane+1, in) in the table, everybody reads, then they store the spin after their op.  Two
@@ -426,24 +461,26 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 }
             }
             const uint32_t sub = sa | (two ? (sc << 1) : 0u);
-            // weight of the diagonal op this slot would get (qmc_ising.rs:863-888); an op already in the string has
-            // its bond's weight (it was inserted with non-zero weight and the string is consistent)
-            const double w_ins = bond_weight(d, sub, sub);
-            const double w = is_empty ? w_ins : d.w;
+            // Would a diagonal op on this bond have non-zero weight here (qmc_ising.rs:863-888)?  Two-site: the spins'
+            // alignment equals the bond's preference; longitudinal: the spin equals the field's; transverse: always.
+            // An op already in the string has its bond's weight (it was inserted with non-zero weight and the string
+            // is consistent).
+            const uint32_t agree = two ? ((sa ^ sc) ^ 1u) : sa;
+            const bool ok = tr | (agree == pref);
             const double uacc = u01(HB ? r0 : r1);
             bool ins;
             if (HB) {
                 // insert: u*(den + bW) < bW after the bond was chosen and kept with u1*maxw < w (heatbath.rs:163-193)
-                ins = is_empty & (u01(r1) * d.w < w_ins);
+                const double w_ins = ok ? wbond : 0.0;
+                ins = is_empty & (u01(r1) * wbond < w_ins);
                 fa[j] = (ins | is_diag) ? uacc : inf;
                 fb[j] = 0.0;
             } else {
-                const double num = beta_nb * w;
-                ins = is_empty & (w_ins > 0.0);
+                ins = is_empty & ok & (nbond > 0.0);
                 // insert: u*den < num          (fa = u, fb = num)
                 // remove: u*num < den          (fa = u*num)
-                fa[j] = ins ? uacc : (is_diag ? uacc * num : inf);
-                fb[j] = num;
+                fa[j] = ins ? uacc : (is_diag ? uacc * nbond : inf);
+                fb[j] = nbond;
             }
             insm[j] = __ballot(ins);
             cb[j] = M + (ins ? 0u : 1u);
