@@ -249,6 +249,9 @@ __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, ui
     return d;
 }
 
+// wave64 ballot straight from the i1 condition (HIP's __ballot(int) goes through a 0/1 integer: v_cndmask + v_cmp_ne)
+__device__ __forceinline__ uint64_t sse_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool sse_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 
@@ -429,7 +432,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             // sub-round.  The op word itself carries the spin before (in) and after (out), so the event lanes
             // publish (lane+1, in) in the table, everybody reads, then they store the spin after their op.  Two
             // events on one variable inside a sub-round are rare; a serial loop over the event lanes handles them.
-            const uint64_t ev0 = SSE_DBG(B, 16u) ? 0ull : __ballot(isev);
+            const uint64_t ev0 = SSE_DBG(B, 16u) ? 0ull : sse_ballot(isev);
             if (ev0) {
                 if (isev) LDSH(L.o_cur, h_my + va) = (uint16_t)((((uint32_t)lane + 1u) << 1) | inb);
                 SSE_WAVE_FENCE();
@@ -438,7 +441,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             uint32_t sa = ea & 1u, sc = ec & 1u;
             if (ev0) {
                 const uint32_t La = ea >> 1, Lc = ec >> 1;
-                const uint64_t dup = __ballot(isev & (La != (uint32_t)lane + 1u));
+                const uint64_t dup = sse_ballot(isev & (La != (uint32_t)lane + 1u));
                 if (!dup) {
                     sa ^= (uint32_t)((La - 1u) < (uint32_t)lane); // La == 0: no event on the variable
                     sc ^= (uint32_t)((Lc - 1u) < (uint32_t)lane);
@@ -482,7 +485,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 fa[j] = ins ? uacc : (is_diag ? uacc * nbond : inf);
                 fb[j] = nbond;
             }
-            insm[j] = __ballot(ins);
+            insm[j] = sse_ballot(ins);
             cb[j] = M + (ins ? 0u : 1u);
             cw[j] = ins ? sse_op_make(b, sub, sub) : 0u;
             keep[j] = wd;
@@ -507,11 +510,11 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 uint64_t lt_ins, lt_rem;
                 if (HB) {
                     const double lhs = fa[j] * (t + hb_bw);
-                    lt_ins = __ballot(lhs < hb_bw);
-                    lt_rem = __ballot(lhs < t);
+                    lt_ins = sse_ballot(lhs < hb_bw);
+                    lt_rem = sse_ballot(lhs < t);
                 } else {
-                    lt_ins = __ballot(fa[j] * t < fb[j]);
-                    lt_rem = __ballot(fa[j] < t);
+                    lt_ins = sse_ballot(fa[j] * t < fb[j]);
+                    lt_rem = sse_ballot(fa[j] < t);
                 }
                 acc[j] = (lt_ins & insm[j]) | (lt_rem & ~insm[j]);
                 changed |= acc[j] != accp[j];
@@ -567,7 +570,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         for (int j = 0; j < K; ++j) {
             ops[slot_of<W, K>(tile, wave, j, lane)] = ((acc[j] >> lane) & 1ull) ? cw[j] : keep[j];
             const uint64_t im = acc[j] & insm[j], rm = acc[j] & ~insm[j];
-            const uint64_t trm = __ballot((trbits >> j) & 1u);
+            const uint64_t trm = sse_ballot((trbits >> j) & 1u);
             dn += popc64(im) - popc64(rm);
             dtr += popc64(im & trm) - popc64(rm & trm);
         }
@@ -731,7 +734,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             const bool two = nonempty & (d.c != SSE_NO_VAR);
             const uint32_t vc = two ? d.c : va;
             const bool iscut = nonempty & (kind == SSE_BOND_TRANSVERSE);
-            const uint64_t cutmask = __ballot(iscut);
+            const uint64_t cutmask = sse_ballot(iscut);
             const uint32_t first = idbase + nlocal + 1u;
             const uint32_t kown = popc64(cutmask & lanemask_lt(lane)); // cuts of this sub-round at earlier lanes
             const uint32_t id_own = first + kown;
@@ -751,7 +754,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             uint32_t seg_c = xc ? idbase + xc : my_placeholder_base + vc;
             if (cutmask) {
                 const uint32_t myrank1 = id_own - idbase; // rank+1 of this lane's cut inside the wave's range
-                const uint64_t dup = __ballot(iscut & (ma != kown + 1u));
+                const uint64_t dup = sse_ballot(iscut & (ma != kown + 1u));
                 if (!dup) {
                     seg_a = ((ma - 1u) < kown) ? first + (ma - 1u) : seg_a; // ma == 0: no cut on the variable
                     seg_c = ((mc - 1u) < kown) ? first + (mc - 1u) : seg_c;
@@ -836,7 +839,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
                     const bool redo = slow[j] | (link[j] & (chk[j] != lo[j]));
-                    if (__any(redo)) { if (redo) uf_union_wave(uf, pa[j], pc[j]); }
+                    if (sse_any(redo)) { if (redo) uf_union_wave(uf, pa[j], pc[j]); }
                 }
             }
         }
@@ -1069,7 +1072,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
 #pragma unroll
         for (int j = 0; j < U; ++j) { const uint32_t p = q0 + (uint32_t)(wave * 64 * U + j * 64 + lane); wd[j] = p < qend ? ops[p] : 0u; }
 #pragma unroll
-        for (int j = 0; j < U; ++j) { occ[j] = __ballot(wd[j] != 0u); cnt += popc64(occ[j]); }
+        for (int j = 0; j < U; ++j) { occ[j] = sse_ballot(wd[j] != 0u); cnt += popc64(occ[j]); }
         const int buf = gr & 1;
         if (lane == 0) LDSI(L.o_tot, buf * W + wave) = cnt;
         __syncthreads();
@@ -1161,7 +1164,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
                     const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
                     match = d.a == var || d.c == var;
                 }
-                const uint64_t mm = __ballot(match);
+                const uint64_t mm = sse_ballot(match);
                 if (mm) best = d0 + (uint32_t)(j * NT + wave * 64) + (uint32_t)(__ffsll((long long)mm) - 1);
             }
             if (best != 0xFFFFFFFFu && lane == 0) atomicMin(&LDSW(L.o_misc, MISC_LOOP_D), best);

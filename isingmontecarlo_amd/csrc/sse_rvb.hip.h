@@ -399,7 +399,7 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
                 const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
                 match = v2s_get(R, d.a) != 0xFFFFu || (d.c != SSE_NO_VAR && v2s_get(R, d.c) != 0xFFFFu);
             }
-            mm[j] = __ballot(match);
+            mm[j] = sse_ballot(match);
             cnt += popc64(mm[j]);
         }
         const int buf = gr & 1;
