@@ -951,10 +951,59 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     }
     __syncthreads();
     SSE_STAMP(3);
-    // ---- coins: each thread reads only parent[i] of its own ids, so parent[i] := flip bit in place ----
+    // ---- coins: one Philox draw per ROOT (= per cluster), then parent[i] := flip bit of its root, in place ----
+    // LDS path: the roots are compacted into a list (wave ballot + one LDS counter) so that the draws run on dense
+    // lanes; the list lives in the cut-marker tables and the flip bits in the cut-rank tables, both free after the
+    // join.  Too many roots or ids for those tables (or no cut at all, or the HBM union-find): every id draws the
+    // coin of its root itself — same results, more Philox calls.
     uint32_t myclusters = 0;
     const bool nocuts = (C == 0u);
     const uint32_t anyfrozen = LDSW(L.o_misc, MISC_ANYFROZEN);
+    bool dense_done = false;
+    if constexpr (!UF_GLOBAL) {
+        const uint32_t list_cap = ((uint32_t)W * N + 3u) / 4u * 2u;  // u16 entries in the o_cl words
+        const uint32_t bits_cap = ((uint32_t)W * N + 1u) / 2u * 32u; // bits in the o_cur words
+        if (!nocuts && S <= bits_cap) {
+            for (uint32_t i = tid; i < (S + 31u) / 32u; i += NT) LDSW(L.o_cur, i) = 0u;
+            if (tid == 0) LDSW(L.o_misc, MISC_LOOP_A) = 0u;
+            __syncthreads();
+            for (uint32_t i0 = 0; i0 < S; i0 += NT) { // whole waves iterate together (ballot below)
+                const uint32_t i = i0 + tid;
+                const bool inr = i < S;
+                const uint32_t root = inr ? uf.get(i) : 0xFFFFFFFFu;
+                const bool isroot = inr & (root == i);
+                if (isroot & (i < N + C)) {
+                    const bool touched = (i >= N) || ((LDSW(L.o_touch, i >> 5) >> (i & 31)) & 1u);
+                    if (touched) myclusters++;
+                }
+                const uint64_t m = sse_ballot(isroot);
+                if (m) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&LDSW(L.o_misc, MISC_LOOP_A), (uint32_t)popc64(m));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t pos = base + popc64(m & lanemask_lt(lane));
+                    if (isroot && pos < list_cap) LDSH(L.o_cl, pos) = (uint16_t)i;
+                }
+            }
+            __syncthreads();
+            const uint32_t nroots = LDSW(L.o_misc, MISC_LOOP_A);
+            if (nroots <= list_cap) { // uniform: every thread read the same counter
+                for (uint32_t k = tid; k < nroots; k += NT) {
+                    const uint32_t root = LDSH(L.o_cl, k);
+                    const uint4 o = rng.draw(SSE_TAG_CLUSTER, root);
+                    const uint32_t isfrozen = B.has_long ? (uf.froot_get(root >> 5) >> (root & 31)) & 1u : 0u;
+                    if (!isfrozen && u01(o.x) < prob) atomicOr(&LDSW(L.o_cur, root >> 5), 1u << (root & 31));
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < S; i += NT) {
+                    const uint32_t root = uf.get(i);
+                    uf.set(i, (LDSW(L.o_cur, root >> 5) >> (root & 31)) & 1u);
+                }
+                dense_done = true;
+            } else myclusters = 0; // counted again below
+        }
+    }
+    if (!dense_done)
     for (uint32_t i = tid; i < S; i += NT) {
         const uint32_t root = uf.get(i);
         const uint32_t vi = i < N ? i : (i - N - C) % N; // variable of a placeholder id (nocuts: every id is one)
