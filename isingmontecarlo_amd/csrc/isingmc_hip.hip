@@ -129,7 +129,7 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
 }
 
 static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges) {
-    return (size_t)nwords * (W + 2) + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + 64 * W + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
+    return (size_t)nwords * (W + 2) + ((size_t)N + 3) / 4 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + 64 * W + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
 }
 
 // LDS footprint of the next launch.  The union-find of the cluster pass lives in LDS as 16-bit parents when all

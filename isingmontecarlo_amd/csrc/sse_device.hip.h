@@ -188,6 +188,7 @@ struct Lds {           // word offsets into lds_raw
     uint32_t o_state;  // [nwords]      p=0 spin state
     uint32_t o_scopy;  // [W][nwords]   spin-state copies (XOR scan)
     uint32_t o_touch;  // [nwords]      variables touched by any op
+    uint32_t o_touch8; // [N] u8        the same as bytes while the cluster scan runs (plain byte stores instead of atomics)
     uint32_t o_tot;    // [2][W]        per-wave totals (double buffered by round parity)
     uint32_t o_chg;    // [2][W]
     uint32_t o_misc;   // [16]
@@ -205,6 +206,7 @@ struct Lds {           // word offsets into lds_raw
         o_state = base; base += nwords;
         o_scopy = base; base += W * nwords;
         o_touch = base; base += nwords;
+        o_touch8 = base; base += (N + 3) / 4;
         o_tot = base; base += 2 * W;
         o_chg = base; base += 2 * W;
         o_misc = base; base += 16;
@@ -782,13 +784,10 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             nlocal += popc64(cutmask);
             if (!APPLY) {
                 if (iscut) uf.set(id_own, id_own);
-                if (nonempty) {
-                    atomicOr(&LDSW(L.o_touch, va >> 5), 1u << (va & 31));
-                    atomicOr(&LDSW(L.o_touch, vc >> 5), 1u << (vc & 31));
-                }
+                if (nonempty) { LDSB(L.o_touch8, va) = (uint8_t)1; LDSB(L.o_touch8, vc) = (uint8_t)1; }
                 ua[j] = seg_a; uc[j] = seg_c;
                 utwo[j] = two & !SSE_DBG(B, 1u); // diagnostic builds: bit 0 = time the scan without unions
-                if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
+                if (B.has_long) if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
                 if constexpr (!G) { // ids fit 16 bits on this path: remember them for the apply pass
                     const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
                     B.segs[(size_t)r * B.stride + p0 + j * 64 + lane] = seg_a | (hi << 16);
@@ -908,6 +907,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
         uf.o_parent = L.o_parent; uf.o_frozen = L.o_frozen; uf.o_froot = L.o_froot;
     }
     for (uint32_t i = tid; i < nwords; i += NT) LDSW(L.o_touch, i) = 0u;
+    for (uint32_t i = tid; i < (N + 3) / 4; i += NT) LDSW(L.o_touch8, i) = 0u;
     if (tid == 0) { LDSW(L.o_misc, MISC_NCLUST) = 0u; LDSW(L.o_misc, MISC_ANYFROZEN) = 0u; }
     if (n == 0) { __syncthreads(); return 0u; } // cluster.rs:46-48
     SSE_STAMP_INIT;
@@ -930,6 +930,15 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     // ---- build: label legs with segment ids, union through non-boundary ops ----
     SSE_STAMP(0);
     cluster_scan<W, K, CL, false, UF_GLOBAL>(B, L, r, M, uf, C);
+    // touched bytes -> bits (read by the coins, the p=0 state update and the free-spin pass, all behind later barriers)
+    for (uint32_t i = tid; i < nwords; i += NT) {
+        uint32_t bits = 0;
+        for (uint32_t k = 0; k < 8 && (i * 8 + k) < (N + 3) / 4; ++k) {
+            const uint32_t w = LDSW(L.o_touch8, i * 8 + k);
+            bits |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * k);
+        }
+        LDSW(L.o_touch, i) = bits;
+    }
     SSE_STAMP(1);
     // join the ranges: the segment v is in when wave w's range ends continues into P(w+1,v); the last
     // range wraps around into P(0,v) (cluster.rs:223-242: worldlines are cyclic in imaginary time)
