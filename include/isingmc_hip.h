@@ -122,6 +122,11 @@ int isingmc_get_n(isingmc_batch *b, uint32_t *out);
 int isingmc_get_cutoff(isingmc_batch *b, uint32_t *out);
 int isingmc_set_cutoff(isingmc_batch *b, uint32_t r, uint32_t cutoff);
 int isingmc_get_epoch(isingmc_batch *b, uint64_t *out);
+/* OpContainer::itime_fold (fast_ops.rs:1296-1315; QmcStepper::imaginary_time_fold, qmc_ising.rs:815-821) for the
+ * magnetisation m = sum_v (2 s_v - 1) of the propagated state: per replica the sums over p = 0..cutoff-1 of m, m^2
+ * and |m| (divide by the cutoff for imaginary-time averages).  Arbitrary closures fold on the host over
+ * isingmc_export_ops. */
+int isingmc_itime_magnetization(isingmc_batch *b, int64_t *sum_m, uint64_t *sum_m2, uint64_t *sum_abs_m);
 /* OpContainer::get_count (op_container.rs:129; fast_ops.rs:1281-1294) */
 int isingmc_get_bond_count(isingmc_batch *b, uint32_t r, uint32_t bond, uint32_t *out);
 /* get_pth for every p (op_container.rs:127): words[cutoff] in the sse_format.h encoding */

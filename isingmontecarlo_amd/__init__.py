@@ -78,6 +78,7 @@ SYMBOLS = {
     "isingmc_last_kernel_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
     "isingmc_last_pass_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
     "isingmc_get_offsets": (C.c_int, [_vp, _P(C.c_double)]),
+    "isingmc_itime_magnetization": (C.c_int, [_vp, _P(C.c_int64), _P(C.c_uint64), _P(C.c_uint64)]),
     "isingmc_get_launch_info": (C.c_int, [_vp, _P(_u32)]),
 }
 
@@ -269,6 +270,32 @@ class QmcIsingGraph:
 
     def get_offset(self):
         return self._lib.isingmc_get_offset(self._h)
+
+    def itime_magnetization(self):
+        """imaginary_time_fold (qmc_ising.rs:815-821) of the magnetisation m = sum_v (2 s_v - 1): per replica the sums over
+        p = 0..cutoff-1 of (m, m^2, |m|), computed on the device.  Divide by get_cutoff() for imaginary-time averages."""
+        a = np.zeros(self.nreplicas, dtype=np.int64)
+        b = np.zeros(self.nreplicas, dtype=np.uint64)
+        c = np.zeros(self.nreplicas, dtype=np.uint64)
+        self._check(self._lib.isingmc_itime_magnetization(self._h, _ptr(a, C.c_int64), _ptr(b, C.c_uint64), _ptr(c, C.c_uint64)))
+        return a, b, c
+
+    def imaginary_time_fold(self, fold_fn, init, r=0):
+        """QmcStepper::imaginary_time_fold (qmc_ising.rs:815-821) with an arbitrary Python closure fold_fn(acc, state)
+        for replica r: folds on the host over the exported op-string (fast_ops.rs:1296-1315)."""
+        state = self.state_ref()[r].astype(bool).copy()
+        ops = self.export_ops(r)
+        e = self.edges
+        acc = init
+        for w in ops:
+            acc = fold_fn(acc, state)
+            if w:
+                bond, _, out = op_fields(int(w))
+                if bond < len(e):
+                    state[e[bond, 0]] = bool(out & 1); state[e[bond, 1]] = bool(out & 2)
+                else:
+                    state[(bond - len(e)) % self.nvars] = bool(out & 1)
+        return acc
 
     def get_offsets(self):
         """Energy offset of every replica (they differ only with per-replica couplings)."""

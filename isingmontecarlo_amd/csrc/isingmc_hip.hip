@@ -128,6 +128,51 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
     ok[r] = good ? 1 : 0;
 }
 
+// OpContainer::itime_fold (fast_ops.rs:1296-1315) for the magnetisation: sums over p = 0..cutoff-1 of m, m^2, |m| of
+// the propagated state BEFORE slot p's op, m = sum_v (2 s_v - 1).  m only moves at off-diagonal ops (+-2 per flipped
+// spin), so every thread takes a contiguous block of slots: block deltas -> exclusive prefix over the workgroup ->
+// each thread replays its block from its starting m.  One workgroup of 256 threads per replica.
+__global__ __launch_bounds__(256) void itime_magnetization_kernel(DevBatch B, long long *sum_m, unsigned long long *sum_m2,
+                                                                  unsigned long long *sum_abs) {
+    __shared__ long long sh[256];
+    __shared__ long long red[3][4];
+    const uint32_t r = blockIdx.x, tid = threadIdx.x;
+    const uint32_t M = B.cutoff[r];
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
+    long long m0 = 0;
+    for (uint32_t i = tid; i < B.nwords; i += 256) m0 += 2ll * __popc(B.state[(size_t)r * B.nwords + i]);
+    for (int off = 32; off > 0; off >>= 1) m0 += __shfl_down(m0, off);
+    if ((tid & 63) == 0) red[0][tid >> 6] = m0;
+    const uint32_t per = (M + 255u) / 256u, p_lo = min(tid * per, M), p_hi = min(p_lo + per, M);
+    auto delta = [](uint32_t w) -> long long {
+        const uint32_t x = sse_op_in(w), y = sse_op_out(w);
+        return 2ll * ((long long)(y & 1u) - (long long)(x & 1u) + (long long)((y >> 1) & 1u) - (long long)((x >> 1) & 1u));
+    };
+    long long d = 0;
+    for (uint32_t p = p_lo; p < p_hi; ++p) d += delta(ops[p]);
+    sh[tid] = d;
+    __syncthreads();
+    long long m = red[0][0] + red[0][1] + red[0][2] + red[0][3] - (long long)B.N; // popcount bits outside N are zero
+    for (uint32_t t = 0; t < tid; ++t) m += sh[t];
+    long long s1 = 0;
+    unsigned long long s2 = 0, sa = 0;
+    for (uint32_t p = p_lo; p < p_hi; ++p) {
+        s1 += m; s2 += (unsigned long long)(m * m); sa += (unsigned long long)(m < 0 ? -m : m);
+        m += delta(ops[p]);
+    }
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); sa += __shfl_down(sa, off);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = (long long)s2; red[2][tid >> 6] = (long long)sa; }
+    __syncthreads();
+    if (tid == 0) {
+        sum_m[r] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        sum_m2[r] = (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        sum_abs[r] = (unsigned long long)(red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    }
+}
+
 static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges) {
     return (size_t)nwords * (W + 2) + ((size_t)N + 3) / 4 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + 64 * W + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
 }
@@ -747,6 +792,25 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
     HIP_TRY(b, hipMemcpy(b->dev.ntrans + r, &ntr, 4, hipMemcpyHostToDevice));
     if (ntr > b->max_ntrans) b->max_ntrans = ntr;
     HIP_TRY(b, hipMemcpy(b->dev.chunks + (size_t)r * 2 * SSE_MAX_CHUNKS, chunks.data(), sizeof(uint32_t) * chunks.size(), hipMemcpyHostToDevice));
+    return ISINGMC_OK;
+}
+int isingmc_itime_magnetization(isingmc_batch *b, int64_t *sum_m, uint64_t *sum_m2, uint64_t *sum_abs_m) {
+    if (!b || !sum_m || !sum_m2 || !sum_abs_m) { if (b) b->err = "bad arguments to itime_magnetization"; return ISINGMC_EINVAL; }
+    HIP_TRY(b, hipSetDevice(b->device));
+    const uint32_t R = b->dev.R;
+    long long *d1 = nullptr; unsigned long long *d2 = nullptr, *d3 = nullptr;
+    HIP_TRY(b, hipMalloc(&d1, sizeof(long long) * R));
+    if (hipMalloc(&d2, sizeof(unsigned long long) * R) != hipSuccess || hipMalloc(&d3, sizeof(unsigned long long) * R) != hipSuccess) {
+        (void)hipFree(d1); if (d2) (void)hipFree(d2);
+        b->err = "itime_magnetization: allocation failed"; return ISINGMC_ENODEVICE;
+    }
+    hipLaunchKernelGGL(itime_magnetization_kernel, dim3(R), dim3(256), 0, b->stream, b->dev, d1, d2, d3);
+    hipError_t e = hipStreamSynchronize(b->stream);
+    if (e == hipSuccess) e = hipMemcpy(sum_m, d1, sizeof(long long) * R, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(sum_m2, d2, sizeof(unsigned long long) * R, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(sum_abs_m, d3, sizeof(unsigned long long) * R, hipMemcpyDeviceToHost);
+    (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(d3);
+    if (e != hipSuccess) { b->err = std::string("itime_magnetization: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; }
     return ISINGMC_OK;
 }
 int isingmc_get_bond_count(isingmc_batch *b, uint32_t r, uint32_t bond, uint32_t *out) {

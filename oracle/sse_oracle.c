@@ -531,6 +531,26 @@ int ora_verify(const ora_replica *r) {
     return ok;
 }
 
+/* Imaginary-time fold of the magnetisation (OpContainer::itime_fold, fast_ops.rs:1296-1315, with the closure
+ * acc + f(m(state)) for f = m, m^2, |m|; m = sum_v (2 s_v - 1)): the fold visits the propagated state BEFORE the op
+ * of every slot p = 0..cutoff-1. */
+void ora_itime_magnetization(const ora_replica *r, int64_t *sum_m, uint64_t *sum_m2, uint64_t *sum_abs) {
+    const ora_model *m = r->m;
+    int64_t mag = 0;
+    for (uint32_t v = 0; v < m->nvars; ++v) mag += r->state[v] ? 1 : -1;
+    int64_t s1 = 0;
+    uint64_t s2 = 0, sa = 0;
+    for (uint32_t p = 0; p < r->cutoff; ++p) {
+        s1 += mag; s2 += (uint64_t)(mag * mag); sa += (uint64_t)(mag < 0 ? -mag : mag);
+        const uint32_t w = r->ops[p];
+        if (w == SSE_OP_EMPTY) continue;
+        const uint32_t in = sse_op_in(w), out = sse_op_out(w);
+        mag += 2 * ((int64_t)(out & 1u) - (int64_t)(in & 1u));
+        mag += 2 * ((int64_t)((out >> 1) & 1u) - (int64_t)((in >> 1) & 1u));
+    }
+    *sum_m = s1; *sum_m2 = s2; *sum_abs = sa;
+}
+
 /* ------------------------------------------------------------------------- accessors --- */
 uint32_t ora_get_n(const ora_replica *r) { return r->n; }
 uint32_t ora_get_cutoff(const ora_replica *r) { return r->cutoff; }

@@ -57,6 +57,8 @@ uint32_t ora_remove_doubles(uint32_t *v, uint32_t n);
 int ora_timestep(ora_replica *r, double beta, uint32_t flags);
 int ora_timesteps(ora_replica *r, uint64_t t, double beta, uint32_t sampling_freq, uint32_t flags);
 int ora_verify(const ora_replica *r);
+/* itime_fold (fast_ops.rs:1296-1315) of m, m^2, |m| over p = 0..cutoff-1 */
+void ora_itime_magnetization(const ora_replica *r, int64_t *sum_m, uint64_t *sum_m2, uint64_t *sum_abs);
 
 /* one parallel-tempering step of one chain; by_slot[t] = replica at temperature t (pointers are swapped) */
 uint64_t ora_pt_step(ora_replica **by_slot, const double *betas, uint32_t ntemps, uint64_t seed, uint32_t chain,

@@ -37,6 +37,7 @@ def load():
         "ora_timestep": (C.c_int, [vp, f64, u32]),
         "ora_timesteps": (C.c_int, [vp, u64, f64, u32, u32]),
         "ora_verify": (C.c_int, [vp]),
+        "ora_itime_magnetization": (None, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "ora_get_n": (u32, [vp]),
         "ora_get_cutoff": (u32, [vp]),
         "ora_set_cutoff": (C.c_int, [vp, u32]),
@@ -142,6 +143,11 @@ class Replica:
 
     def verify(self):
         return bool(lib().ora_verify(self.ptr))
+
+    def itime_magnetization(self):
+        a, b, c = C.c_int64(0), C.c_uint64(0), C.c_uint64(0)
+        lib().ora_itime_magnetization(self.ptr, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     @property
     def n(self):

@@ -280,3 +280,20 @@ def test_disorder_realisations_cubic_pm_j(oracle, waves, heatbath):
     assert len(set(int(x) for x in g.get_n())) > 1
     with pytest.raises(im.IsingMcError):
         g.single_rvb_sweep()
+
+
+def test_itime_magnetization_fold(oracle):
+    """imaginary_time_fold of m, m^2, |m| (fast_ops.rs:1296-1315) on the device against the oracle's sequential fold and the
+    generic host-side fold."""
+    edges = lat.two_d_ferro(8)
+    R = 5
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 64, 1 << 13, 99, R)
+    g.run(25, 3.0)
+    oracle.batch_timesteps(reps, 25, [3.0] * R)
+    assert_same(g, reps, "8x8 before fold")
+    s1, s2, sa = g.itime_magnetization()
+    for r, rep in enumerate(reps):
+        assert (int(s1[r]), int(s2[r]), int(sa[r])) == rep.itime_magnetization(), f"replica {r}"
+    mag = lambda st: 2 * int(st.sum()) - len(st)
+    assert g.imaginary_time_fold(lambda acc, st: acc + mag(st) ** 2, 0, r=2) == int(s2[2])
+    assert (np.abs(s1) <= sa.astype(np.int64)).all() and (sa > 0).any()

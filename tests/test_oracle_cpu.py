@@ -195,3 +195,24 @@ def test_rvb_hand_built_opstrings_stay_valid():
                 r.rvb_update(1)
                 assert r.verify()
             assert r.n == n0  # RVB moves and rotates ops, it never changes their number
+
+
+def test_itime_magnetization_matches_python_fold(oracle):
+    """ora_itime_magnetization against a direct Python restatement of itime_fold (fast_ops.rs:1296-1315)."""
+    edges = lat.one_d_periodic(6, -1.0)
+    e, j = lat.split(edges)
+    m = oracle.Model(6, e, j, 1.0, 0.0)
+    rep = oracle.Replica(m, 1 << 10, 16, 5, 0)
+    oracle.batch_timesteps([rep], 40, [2.0])
+    st = rep.state().astype(int).copy()
+    s1 = s2 = sa = 0
+    for w in rep.ops():
+        mag = 2 * int(st.sum()) - len(st)
+        s1 += mag; s2 += mag * mag; sa += abs(mag)
+        if w:
+            bond, out = (int(w) >> 4) - 1, (int(w) >> 2) & 3
+            if bond < len(e):
+                st[e[bond][0]] = out & 1; st[e[bond][1]] = (out >> 1) & 1
+            else:
+                st[(bond - len(e)) % 6] = out & 1
+    assert rep.itime_magnetization() == (s1, s2, sa)
