@@ -97,12 +97,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # SSE_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks then share devices and the
+    # scalar reductions go through CPU tensors); the driver's runs use nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("SSE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     flags = 0 if args.no_loop else im.FLAG_LOOP
     if args.rvb:
@@ -155,7 +163,7 @@ def main():
     kernel_ms, launches = g.last_kernel_ms()
     mean_M = slots / (R * args.steps)
     mean_n = float(acc[:, 0].sum() / max(1.0, acc[:, 1].sum()))
-    t = torch.tensor([dt, updates, slots, kernel_ms], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, updates, slots, kernel_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

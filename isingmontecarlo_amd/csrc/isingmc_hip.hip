@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void itime_magnetization_kernel(DevBatch B, lo
 }
 
 static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges) {
-    return (size_t)nwords * (W + 2) + ((size_t)N + 3) / 4 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + 64 * W + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
+    // mirrors Lds<W>::carve up to and including o_cl: state, touched bits, touched bytes, round buffers, misc, chunk counters,
+    // edge table, per-wave rank tables (u16) and marker tables (u8)
+    return (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
 }
 
 // LDS footprint of the next launch.  The union-find of the cluster pass lives in LDS as 16-bit parents when all

@@ -186,7 +186,6 @@ extern __shared__ __align__(16) uint32_t lds_raw[];
 template <int W>
 struct Lds {           // word offsets into lds_raw
     uint32_t o_state;  // [nwords]      p=0 spin state
-    uint32_t o_scopy;  // [W][nwords]   spin-state copies (XOR scan)
     uint32_t o_touch;  // [nwords]      variables touched by any op
     uint32_t o_touch8; // [N] u8        the same as bytes while the cluster scan runs (plain byte stores instead of atomics)
     uint32_t o_tot;    // [2][W]        per-wave totals (double buffered by round parity)
@@ -194,7 +193,6 @@ struct Lds {           // word offsets into lds_raw
     uint32_t o_misc;   // [16]
     uint32_t o_chn;    // [SSE_MAX_CHUNKS] occupied slots per chunk
     uint32_t o_chtr;   // [SSE_MAX_CHUNKS] transverse ops per chunk
-    uint32_t o_cutlane; // [W][64]      per wave: lane of the k-th cut of the current sub-round
     uint32_t o_edges;  // [E]           compact edge table (CL mode only)
     uint32_t o_cur;    // [W][N] u16    per wave: rank+1 (within the wave's range) of the latest cut on each variable
     uint32_t o_cl;     // [W][N] u8     per wave: 1 + rank inside the current sub-round of a cut on the variable (0 = none)
@@ -204,7 +202,6 @@ struct Lds {           // word offsets into lds_raw
     __device__ __forceinline__ void carve(uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges, uint32_t has_long) {
         uint32_t base = 0;
         o_state = base; base += nwords;
-        o_scopy = base; base += W * nwords;
         o_touch = base; base += nwords;
         o_touch8 = base; base += (N + 3) / 4;
         o_tot = base; base += 2 * W;
@@ -212,7 +209,6 @@ struct Lds {           // word offsets into lds_raw
         o_misc = base; base += 16;
         o_chn = base; base += SSE_MAX_CHUNKS;
         o_chtr = base; base += SSE_MAX_CHUNKS;
-        o_cutlane = base; base += W * 64;
         o_edges = base; base += ledges;
         o_cur = base; base += (W * N + 1) / 2;
         o_cl = base; base += (W * N + 3) / 4;
