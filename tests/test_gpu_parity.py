@@ -297,3 +297,48 @@ def test_itime_magnetization_fold(oracle):
     mag = lambda st: 2 * int(st.sum()) - len(st)
     assert g.imaginary_time_fold(lambda acc, st: acc + mag(st) ** 2, 0, r=2) == int(s2[2])
     assert (np.abs(s1) <= sa.astype(np.int64)).all() and (sa > 0).any()
+
+
+def _random_model(rng):
+    """Random connected graph with random couplings (mixed signs, uniform or non-uniform magnitudes), fields and beta."""
+    n = int(rng.integers(3, 40))
+    edges = {}
+    for v in range(1, n):  # spanning tree first: connected
+        edges[(int(rng.integers(0, v)), v)] = 0.0
+    for _ in range(int(rng.integers(0, 2 * n))):
+        a, b = (int(x) for x in rng.integers(0, n, size=2))
+        if a != b:
+            edges[(min(a, b), max(a, b))] = 0.0
+    uniform = bool(rng.integers(0, 2))
+    out = []
+    for (a, b) in sorted(edges):
+        mag = 1.0 if uniform else float(rng.uniform(0.3, 2.0))
+        out.append(((a, b), mag * (1.0 if rng.integers(0, 2) else -1.0)))
+    gamma = float(rng.choice([0.4, 1.0, 1.7]))
+    h = float(rng.choice([0.0, 0.0, 0.25, -0.6]))
+    beta = float(rng.choice([0.5, 1.5, 3.0]))
+    return out, gamma, h, beta
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_models_all_passes(oracle, seed):
+    """Randomised sweep of the parameter space the fixed cases do not reach: random graphs, couplings, fields, beta, launch
+    geometry, pass combination (Metropolis / heat-bath, with / without directed loop, fused / split launches)."""
+    rng = np.random.default_rng(1000 + seed)
+    edges, gamma, h, beta = _random_model(rng)
+    waves = int(rng.choice([0, 1, 4, 8, 16]))
+    k = int(rng.choice([0, 1, 2, 4]))
+    cfgf = int(rng.choice([0, 1, 2, 3]))
+    flags = int(rng.choice([0, 1, 4, 5]))
+    R = int(rng.integers(1, 7))
+    g, m, reps = make_pair(oracle, edges, gamma, h, 8, 1 << 13, 555 + seed, R, waves=waves, k=k, cfg_flags=cfgf)
+    steps = int(rng.integers(10, 40))
+    g.run(steps, beta, sampling_freq=2, flags=flags)
+    for rep in reps:
+        rep.timesteps(steps, beta, 2, flags)
+    what = f"random model seed={seed} n={g.nvars} E={len(edges)} gamma={gamma} h={h} beta={beta} W={waves} K={k} cfg={cfgf} flags={flags}"
+    assert_same(g, reps, what)
+    acc = g.accumulators()
+    for r, rep in enumerate(reps):
+        assert np.array_equal(acc[r, :7], rep.accumulators()[:7]), what
+    assert g.verify().all(), what
