@@ -122,6 +122,10 @@ int isingmc_get_n(isingmc_batch *b, uint32_t *out);
 int isingmc_get_cutoff(isingmc_batch *b, uint32_t *out);
 int isingmc_set_cutoff(isingmc_batch *b, uint32_t r, uint32_t cutoff);
 int isingmc_get_epoch(isingmc_batch *b, uint64_t *out);
+/* restore the per-replica update counters (the Philox epoch): with isingmc_import_ops / isingmc_set_state /
+ * isingmc_set_cutoffs this makes a resumed batch continue bit-exactly (checkpoint / resume; the reference's serde
+ * support, qmc_ising.rs:1001-1087, serialises the same fields plus its RNG) */
+int isingmc_set_epoch(isingmc_batch *b, const uint64_t *epochs);
 /* OpContainer::itime_fold (fast_ops.rs:1296-1315; QmcStepper::imaginary_time_fold, qmc_ising.rs:815-821) for the
  * magnetisation m = sum_v (2 s_v - 1) of the propagated state: per replica the sums over p = 0..cutoff-1 of m, m^2
  * and |m| (divide by the cutoff for imaginary-time averages).  Arbitrary closures fold on the host over

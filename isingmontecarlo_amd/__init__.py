@@ -78,6 +78,7 @@ SYMBOLS = {
     "isingmc_last_kernel_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
     "isingmc_last_pass_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
     "isingmc_get_offsets": (C.c_int, [_vp, _P(C.c_double)]),
+    "isingmc_set_epoch": (C.c_int, [_vp, _P(C.c_uint64)]),
     "isingmc_itime_magnetization": (C.c_int, [_vp, _P(C.c_int64), _P(C.c_uint64), _P(C.c_uint64)]),
     "isingmc_get_launch_info": (C.c_int, [_vp, _P(_u32)]),
 }
@@ -356,6 +357,36 @@ class QmcIsingGraph:
     def import_ops(self, words, r=0):
         w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
         self._check(self._lib.isingmc_import_ops(self._h, int(r), _ptr(w, C.c_uint32), len(w)))
+
+    # ---- checkpoint / resume (the reference's serde feature, qmc_ising.rs:1001-1087) ----
+    def save_checkpoint(self, path):
+        """Write op-strings, p=0 states, cutoffs, update counters and accumulators of every replica to an .npz file.
+        A batch built with the same model and seed and restored with load_checkpoint continues bit-exactly."""
+        cut = self.get_cutoff()
+        offs = np.zeros(self.nreplicas + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(cut.astype(np.int64))
+        words = np.zeros(int(offs[-1]), dtype=np.uint32)
+        for r in range(self.nreplicas):
+            words[offs[r]:offs[r + 1]] = self.export_ops(r, int(cut[r]))
+        np.savez_compressed(path, format=np.array([1], dtype=np.uint32), nvars=np.array([self.nvars], dtype=np.uint32),
+                            edges=self.edges, J=self.J, transverse=self.transverse, longitudinal=self.longitudinal,
+                            cutoff=cut, offsets=offs, words=words, state=self.state_ref(), epoch=self.get_epoch(),
+                            accumulators=self.accumulators())
+
+    def load_checkpoint(self, path):
+        """Restore what save_checkpoint wrote into this batch (same graph and number of replicas required)."""
+        z = np.load(path, allow_pickle=False)
+        if int(z["nvars"][0]) != self.nvars or not np.array_equal(z["edges"], self.edges) or len(z["cutoff"]) != self.nreplicas:
+            raise IsingMcError(-1, "checkpoint belongs to a different model or batch size")
+        if not np.array_equal(z["J"], self.J) or float(z["transverse"]) != self.transverse or float(z["longitudinal"]) != self.longitudinal:
+            raise IsingMcError(-1, "checkpoint belongs to a different Hamiltonian")
+        offs, words = z["offsets"], z["words"]
+        self.set_state(z["state"])
+        for r in range(self.nreplicas):
+            self.import_ops(words[offs[r]:offs[r + 1]], r)
+        self.set_cutoffs(z["cutoff"])
+        ep = np.ascontiguousarray(z["epoch"].astype(np.uint64))
+        self._check(self._lib.isingmc_set_epoch(self._h, _ptr(ep, C.c_uint64)))
 
     def verify(self):
         out = np.zeros(self.nreplicas, dtype=np.uint8)

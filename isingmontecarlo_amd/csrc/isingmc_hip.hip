@@ -749,6 +749,12 @@ int isingmc_get_epoch(isingmc_batch *b, uint64_t *out) {
     HIP_TRY(b, hipMemcpy(out, b->dev.epoch, sizeof(uint64_t) * b->dev.R, hipMemcpyDeviceToHost));
     return ISINGMC_OK;
 }
+int isingmc_set_epoch(isingmc_batch *b, const uint64_t *epochs) {
+    if (!b || !epochs) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipMemcpy(b->dev.epoch, epochs, sizeof(uint64_t) * b->dev.R, hipMemcpyHostToDevice));
+    return ISINGMC_OK;
+}
 int isingmc_set_cutoff(isingmc_batch *b, uint32_t r, uint32_t cutoff) {
     if (!b || r >= b->dev.R) { if (b) b->err = "bad replica index"; return ISINGMC_EINVAL; }
     if (cutoff > b->dev.cap) { b->err = "cutoff exceeds capacity"; return ISINGMC_ECAPACITY; }

@@ -342,3 +342,42 @@ def test_random_models_all_passes(oracle, seed):
     for r, rep in enumerate(reps):
         assert np.array_equal(acc[r, :7], rep.accumulators()[:7]), what
     assert g.verify().all(), what
+
+
+def test_checkpoint_resume_is_bit_exact(oracle, tmp_path):
+    """save_checkpoint / load_checkpoint: a restored batch continues exactly like the original (and like the oracle)."""
+    import isingmontecarlo_amd as im
+    edges = lat.two_d_periodic(4)
+    R = 4
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.2, 16, 1 << 12, 77, R)
+    g.run(15, 2.0)
+    path = str(tmp_path / "ckpt.npz")
+    g.save_checkpoint(path)
+    g.run(12, 2.0)
+    g2 = im.QmcIsingGraph(edges, 1.0, 0.2, 16, 77, nreplicas=R, capacity=1 << 12)
+    g2.load_checkpoint(path)
+    assert g2.verify().all()
+    g2.run(12, 2.0)
+    oracle.batch_timesteps(reps, 27, [2.0] * R)
+    assert_same(g, reps, "original")
+    assert_same(g2, reps, "resumed")
+    g3 = im.QmcIsingGraph(lat.two_d_periodic(4), 1.0, 0.0, 16, 77, nreplicas=R, capacity=1 << 12)
+    with pytest.raises(im.IsingMcError):
+        g3.load_checkpoint(path)
+
+
+def test_cpp_example_through_the_c_abi(tmp_path):
+    """examples/small_qmc.cpp (the reference's examples/small_qmc.rs from compiled code over include/isingmc_hip.h):
+    builds with g++, runs on the GPU and lands on the exact-diagonalisation energy of the model."""
+    import json, os, subprocess
+    import isingmontecarlo_amd as im
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(im.load_library()._name)
+    exe = str(tmp_path / "small_qmc")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "small_qmc.cpp"),
+                           "-L" + libdir, "-lisingmc_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.check_output([exe, "512"], text=True).split()
+    energy, sem = float(out[1]), float(out[3])
+    golden = json.load(open(os.path.join(root, "tests", "golden", "ed_tfim.json")))
+    exact = next(r["energy"] for c in golden if c["name"] == "small_qmc_ring4" for r in c["results"] if r["beta"] == 1.0)
+    assert abs(energy - exact) < 5 * sem + 1e-3, (energy, sem, exact)
