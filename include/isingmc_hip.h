@@ -72,7 +72,24 @@ typedef struct isingmc_config {
     uint32_t waves_offdiag;     /* wave64s per replica for launches without a diagonal pass (directed loop, cluster,
                                  * free spins): 0 = same as waves_per_replica when that is given, otherwise decided
                                  * per launch (16 while the scan tables and the union-find fit in LDS); 1, 4, 6, 8, 16 */
+    /* Generic interactions (qmc::sse::Qmc, qmc_runner.rs:94-156, Interaction :415-680).  When `interactions` is non-NULL
+     * the batch is built from them and edges / J / transverse / longitudinal are ignored: bond b = interaction b.
+     * Available updates: diagonal (Metropolis or heat-bath), directed loop, free spins; cluster and RVB updates are
+     * Ising-specific and return ISINGMC_ENOTIMPL. */
+    const struct isingmc_interaction *interactions;
+    uint32_t ninteractions;
+    double energy_offset;       /* added to -<n>/beta by isingmc_get_offset (sum of the offsets the caller absorbed,
+                                   Qmc::make_interaction_and_offset) */
 } isingmc_config;
+
+/* One interaction: k = 1 or 2 variables and the 4^k matrix of the reference (Interaction::at, qmc_runner.rs:573-612):
+ * index = outputs then inputs, first variable most significant, i.e. for k = 2  (out0 out1 in0 in1)  as a 4-bit number.
+ * All entries must be >= 0 (they are sampling weights). */
+typedef struct isingmc_interaction {
+    uint32_t nvars;           /* 1 or 2 */
+    uint32_t vars[2];
+    const double *mat;        /* [4^nvars] */
+} isingmc_interaction;
 
 /* QmcIsingGraph::new_with_rng (qmc_ising.rs:131-148) + OpContainerConstructor::new_with_bonds
  * (op_container.rs:110), for R replicas at once. */

@@ -31,6 +31,11 @@ class IsingMcError(RuntimeError):
         self.code = code
 
 
+class _Interaction(C.Structure):
+    """include/isingmc_hip.h: isingmc_interaction"""
+    _fields_ = [("nvars", C.c_uint32), ("vars", C.c_uint32 * 2), ("mat", C.POINTER(C.c_double))]
+
+
 class _Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("nreplicas", C.c_uint32), ("nvars", C.c_uint32),
                 ("nedges", C.c_uint32), ("edges", C.POINTER(C.c_uint32)), ("J", C.POINTER(C.c_double)),
@@ -38,7 +43,8 @@ class _Config(C.Structure):
                 ("cutoff0", C.c_uint32), ("seed", C.c_uint64), ("replica_offset", C.c_uint32),
                 ("device", C.c_int32), ("init_state", C.POINTER(C.c_uint8)),
                 ("waves_per_replica", C.c_uint32), ("slots_per_lane", C.c_uint32), ("flags", C.c_uint32),
-                ("lds_uf_ids_limit", C.c_uint32), ("waves_offdiag", C.c_uint32)]
+                ("lds_uf_ids_limit", C.c_uint32), ("waves_offdiag", C.c_uint32),
+                ("interactions", C.c_void_p), ("ninteractions", C.c_uint32), ("energy_offset", C.c_double)]
 
 
 # every symbol include/isingmc_hip.h declares: name -> (restype, argtypes)
@@ -455,6 +461,70 @@ class Qmc(QmcIsingGraph):
 
     def flip_free_bits(self):
         self.flip_free_spins()
+
+
+    # ---- generic interactions (qmc_runner.rs:94-156, Interaction :415-680) ----
+    @staticmethod
+    def interaction_and_offset(mat):
+        """Interaction::new_offset (qmc_runner.rs:489-502): shift the diagonal so that its minimum is 0; returns the shifted
+        matrix and the amount to subtract from the energy offset (Qmc::make_interaction_and_offset, :108-118)."""
+        m = np.array(mat, dtype=np.float64).copy()
+        tn = int(round(np.sqrt(len(m))))
+        d = np.arange(tn) * (tn + 1)
+        mn = float(m[d].min())
+        m[d] -= mn
+        return m, mn
+
+    @classmethod
+    def from_interactions(cls, nvars, interactions, cutoff, seed, energy_offset=0.0, state=None, nreplicas=1, capacity=None,
+                          replica_offset=0, device=-1, waves_per_replica=0, slots_per_lane=0, do_loop_updates=True):
+        """qmc::sse::Qmc with arbitrary one- and two-variable interactions: `interactions` = [(mat, vars), ...] with
+        mat the reference's 4^k weight matrix (index = outputs then inputs, first variable most significant) and all
+        entries >= 0.  timestep = diagonal update -> directed loop (if enabled) -> free spins; cluster and RVB updates
+        are Ising-specific and not available."""
+        self = cls.__new__(cls)
+        lib = load_library()
+        self._lib, self._h = lib, None
+        self.nvars, self.nreplicas = int(nvars), int(nreplicas)
+        arr = (_Interaction * len(interactions))()
+        keep = []
+        for i, (mat, vs) in enumerate(interactions):
+            m = np.ascontiguousarray(np.asarray(mat, dtype=np.float64))
+            vs = [int(v) for v in vs]
+            if len(m) != 4 ** len(vs) or len(vs) not in (1, 2):
+                raise IsingMcError(-1, "interaction matrices must have 4^k entries for k = 1 or 2 variables")
+            keep.append(m)
+            arr[i].nvars = len(vs)
+            arr[i].vars[0] = vs[0]
+            arr[i].vars[1] = vs[1] if len(vs) == 2 else 0
+            arr[i].mat = m.ctypes.data_as(C.POINTER(C.c_double))
+        self.interactions = [(np.array(m), list(v)) for (m, v) in interactions]
+        # host-side mirrors used by imaginary_time_fold: bond -> variables
+        self.edges = np.zeros((0, 2), dtype=np.uint32)
+        self.J = np.zeros(0)
+        self.transverse = self.longitudinal = 0.0
+        if capacity is None:
+            capacity = max(int(cutoff), 64)
+        init = None
+        if state is not None:
+            st = np.asarray(state, dtype=np.uint8)
+            if st.ndim == 1:
+                st = np.broadcast_to(st, (self.nreplicas, self.nvars))
+            init = np.ascontiguousarray(st)
+        cfg = _Config(struct_size=C.sizeof(_Config), nreplicas=self.nreplicas, nvars=self.nvars, nedges=0,
+                      capacity=int(capacity), cutoff0=int(cutoff), seed=int(seed), replica_offset=int(replica_offset),
+                      device=int(device), init_state=_ptr(init, C.c_uint8) if init is not None else None,
+                      waves_per_replica=int(waves_per_replica), slots_per_lane=int(slots_per_lane),
+                      interactions=C.cast(arr, C.c_void_p), ninteractions=len(interactions), energy_offset=float(energy_offset))
+        h = C.c_void_p()
+        rc = lib.isingmc_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise IsingMcError(rc, lib.isingmc_last_error(None).decode())
+        self._h = h
+        self.capacity = int(capacity)
+        self._flags = FLAG_NO_CLUSTER | (FLAG_LOOP if do_loop_updates else 0)
+        self._acc_rows = self.nreplicas
+        return self
 
 
 from .tempering import TemperingContainer, pt_decide  # noqa: E402

@@ -37,6 +37,8 @@ struct isingmc_batch {
     double offset = 0.0;
     std::vector<double> offsets;        // per-replica energy offsets (ISINGMC_CFG_PER_REPLICA_J), else empty
     bool per_replica_J = false;
+    bool generic = false;               // built from isingmc_interaction matrices
+    std::vector<double> mats_host;      // [Nb][16] in | out<<2
     std::vector<BondRec> bonds_host;
     double *d_beta = nullptr;
     uint32_t *d_out = nullptr;
@@ -109,7 +111,7 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
         Bd d;
         d.a = rec.a_info & SSE_VAR_MASK; d.c = rec.c; d.kp = rec.a_info >> SSE_INFO_SHIFT; d.w = rec.w;
         const uint32_t in = sse_op_in(w), out = sse_op_out(w);
-        if (!(bond_weight(d, in, out) > 2.220446049250313e-16)) good = false;
+        if (!(op_weight(B, b, d, in, out) > 2.220446049250313e-16)) good = false;
         if (bd_kind(d) == SSE_BOND_TRANSVERSE) { ntr++; cctr++; }
         const uint32_t a = d.a, c = d.c;
         if (((s[a >> 5] >> (a & 31)) & 1u) != (in & 1u)) good = false;
@@ -253,6 +255,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         b->err = "beta is required for a diagonal update";
         return ISINGMC_EINVAL;
     }
+    if ((domask & (SSE_DO_RVB | SSE_DO_CLUSTER)) && b->generic) { b->err = "cluster and RVB updates are Ising-specific: not available with generic interactions"; return ISINGMC_ENOTIMPL; }
     if ((domask & SSE_DO_RVB) && b->per_replica_J) { b->err = "RVB updates with per-replica couplings are not implemented"; return ISINGMC_ENOTIMPL; }
     A.sampling_freq = freq;
     A.domask = domask & 0xFFFFu;
@@ -369,11 +372,24 @@ extern "C" {
 int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (!cfg || !out || cfg->struct_size != sizeof(isingmc_config)) { g_create_error = "bad config pointer or struct_size"; return ISINGMC_EINVAL; }
     *out = nullptr;
+    const bool generic = cfg->interactions != nullptr;
+    if (generic) {
+        if (cfg->nreplicas == 0 || cfg->nvars == 0 || cfg->ninteractions == 0) { g_create_error = "nreplicas, nvars, ninteractions must be > 0"; return ISINGMC_EINVAL; }
+        if (cfg->flags & ISINGMC_CFG_PER_REPLICA_J) { g_create_error = "per-replica couplings are not available with generic interactions"; return ISINGMC_EINVAL; }
+        for (uint32_t i = 0; i < cfg->ninteractions; ++i) {
+            const isingmc_interaction &it = cfg->interactions[i];
+            if ((it.nvars != 1 && it.nvars != 2) || !it.mat || it.vars[0] >= cfg->nvars || (it.nvars == 2 && (it.vars[1] >= cfg->nvars || it.vars[1] == it.vars[0]))) {
+                g_create_error = "interaction must act on 1 or 2 distinct variables inside the model and carry a matrix"; return ISINGMC_EINVAL;
+            }
+            for (uint32_t k = 0; k < (it.nvars == 2 ? 16u : 4u); ++k)
+                if (!(it.mat[k] >= 0.0) || !std::isfinite(it.mat[k])) { g_create_error = "interaction matrix entries must be finite and >= 0"; return ISINGMC_EINVAL; }
+        }
+    } else
     if (cfg->nreplicas == 0 || cfg->nvars == 0 || cfg->nedges == 0 || !cfg->edges || !cfg->J) { g_create_error = "nreplicas, nvars, nedges must be > 0 and edges/J non-null"; return ISINGMC_EINVAL; }
     if (cfg->cutoff0 > cfg->capacity) { g_create_error = "cutoff0 exceeds capacity"; return ISINGMC_EINVAL; }
     if (cfg->nvars > SSE_VAR_MASK) { g_create_error = "too many variables"; return ISINGMC_EINVAL; }
-    if (!(cfg->transverse >= 0.0)) { g_create_error = "transverse field must be >= 0"; return ISINGMC_EINVAL; }
-    for (uint32_t e = 0; e < cfg->nedges; ++e)
+    if (!generic && !(cfg->transverse >= 0.0)) { g_create_error = "transverse field must be >= 0"; return ISINGMC_EINVAL; }
+    for (uint32_t e = 0; !generic && e < cfg->nedges; ++e)
         if (cfg->edges[2 * e] >= cfg->nvars || cfg->edges[2 * e + 1] >= cfg->nvars || cfg->edges[2 * e] == cfg->edges[2 * e + 1]) {
             g_create_error = "edge endpoint out of range";
             return ISINGMC_EINVAL;
@@ -388,9 +404,10 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (hipSetDevice(dev) != hipSuccess) { b->err = "hipSetDevice failed"; return fail(ISINGMC_ENODEVICE); }
 
     DevBatch &D = b->dev;
-    const bool has_long = std::fabs(cfg->longitudinal) > DBL_EPSILON; // qmc_ising.rs:230
-    D.R = cfg->nreplicas; D.N = cfg->nvars; D.E = cfg->nedges;
-    D.Nb = cfg->nedges + cfg->nvars + (has_long ? cfg->nvars : 0);
+    const bool has_long = !generic && std::fabs(cfg->longitudinal) > DBL_EPSILON; // qmc_ising.rs:230
+    b->generic = generic;
+    D.R = cfg->nreplicas; D.N = cfg->nvars; D.E = generic ? 0u : cfg->nedges;
+    D.Nb = generic ? cfg->ninteractions : cfg->nedges + cfg->nvars + (has_long ? cfg->nvars : 0);
     if (D.Nb > SSE_MAX_BONDS) { b->err = "too many bonds"; return fail(ISINGMC_EINVAL); }
     D.cap = cfg->capacity; D.nwords = (cfg->nvars + 31) / 32;
     D.seed_lo = (uint32_t)cfg->seed; D.seed_hi = (uint32_t)(cfg->seed >> 32);
@@ -405,7 +422,40 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     tab.resize((size_t)nH * D.Nb);
     std::vector<double> cum((size_t)nH * D.Nb), wtots(nH);
     if (perJ) b->offsets.resize(nH);
-    for (uint32_t hI = 0; hI < nH; ++hI) {
+    if (generic) {
+        // bond b = interaction b.  Weights go to mats[b][in | out<<2] (bit 0 = first variable); the reference's index
+        // is (out0 out1 in0 in1) with the first variable most significant (Interaction::index_from_state,
+        // qmc_runner.rs:666-679).  Kinds only feed the transverse-op counters: a one-variable interaction with four
+        // equal entries is a cluster edge (cluster.rs:284-286).
+        b->mats_host.assign((size_t)D.Nb * 16, 0.0);
+        double c = 0.0;
+        for (uint32_t i = 0; i < D.Nb; ++i) {
+            const isingmc_interaction &it = cfg->interactions[i];
+            double *mb = b->mats_host.data() + (size_t)i * 16;
+            if (it.nvars == 2) {
+                for (uint32_t in = 0; in < 4; ++in)
+                    for (uint32_t out = 0; out < 4; ++out) {
+                        const uint32_t ref = ((out & 1u) << 3) | (((out >> 1) & 1u) << 2) | ((in & 1u) << 1) | ((in >> 1) & 1u);
+                        mb[in | (out << 2)] = it.mat[ref];
+                    }
+            } else {
+                for (uint32_t in = 0; in < 2; ++in)
+                    for (uint32_t out = 0; out < 2; ++out) mb[in | (out << 2)] = it.mat[(out << 1) | in];
+            }
+            double maxw = 0.0; // heatbath.rs:130-146 make_bond_weights: largest diagonal element
+            for (uint32_t st = 0; st < (it.nvars == 2 ? 4u : 2u); ++st) maxw = std::max(maxw, mb[st | (st << 2)]);
+            const uint32_t kind = it.nvars == 2 ? SSE_BOND_TWO_SITE
+                                  : ((mb[0] == mb[1] && mb[0] == mb[4] && mb[0] == mb[5]) ? SSE_BOND_TRANSVERSE : SSE_BOND_LONGITUDINAL);
+            tab[i].a_info = it.vars[0] | (kind << SSE_INFO_SHIFT);
+            tab[i].c = it.nvars == 2 ? it.vars[1] : SSE_NO_VAR;
+            tab[i].w = maxw;
+            c = (i == 0) ? maxw : maxw + c;
+            cum[i] = c;
+        }
+        wtots[0] = c;
+        b->offset = cfg->energy_offset;
+    }
+    for (uint32_t hI = 0; !generic && hI < nH; ++hI) {
         BondRec *t0 = tab.data() + (size_t)hI * D.Nb;
         const double *Jh = cfg->J + (size_t)hI * D.E;
         double off = 0.0;
@@ -452,7 +502,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     for (uint32_t hI = 0; hI < nH && D.uniformJ; ++hI)
         for (uint32_t e = 0; e < D.E; ++e) if (tab[(size_t)hI * D.Nb + e].w != tab[0].w) { D.uniformJ = 0u; break; }
     b->fused_launch = (cfg->flags & ISINGMC_CFG_FUSED_LAUNCH) != 0;
-    const bool CL = !perJ && D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
+    const bool CL = !generic && !perJ && D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
     const uint32_t ledges = CL ? D.E : 0u;
     while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : (W == 6 ? 4 : W >> 1);
     const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges);
@@ -557,6 +607,12 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if ((rc = dalloc(b, &b->d_ok, D.R))) return fail(rc);
     if (hipMemcpy(dbonds, tab.data(), sizeof(BondRec) * (size_t)nH * D.Nb, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dcum, cum.data(), sizeof(double) * (size_t)nH * D.Nb, hipMemcpyHostToDevice) != hipSuccess) { b->err = "table upload failed"; return fail(ISINGMC_ENODEVICE); }
+    if (generic) {
+        double *dm = nullptr;
+        if ((rc = dalloc(b, &dm, b->mats_host.size(), false))) return fail(rc);
+        if (hipMemcpy(dm, b->mats_host.data(), sizeof(double) * b->mats_host.size(), hipMemcpyHostToDevice) != hipSuccess) { b->err = "matrix upload failed"; return fail(ISINGMC_ENODEVICE); }
+        D.mats = dm;
+    }
     std::vector<uint32_t> cut(D.R, cfg->cutoff0);
     if (hipMemcpy(D.cutoff, cut.data(), sizeof(uint32_t) * D.R, hipMemcpyHostToDevice) != hipSuccess) { b->err = "cutoff upload failed"; return fail(ISINGMC_ENODEVICE); }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { b->err = "hipEventCreate failed"; return fail(ISINGMC_ENODEVICE); }
@@ -783,6 +839,9 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
         if (bond >= b->dev.Nb) { b->err = "op refers to a bond outside the model"; return ISINGMC_EINVAL; }
         // Ising bonds: two-site and longitudinal ops have zero off-diagonal weight (qmc_ising.rs:863-888)
         const uint32_t kind = (b->bonds_host[hoff + bond].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK;
+        if (b->generic) {
+            if (!(b->mats_host[(size_t)bond * 16 + (sse_op_in(words[p]) | (sse_op_out(words[p]) << 2))] > 0.0)) { b->err = "op with zero weight"; return ISINGMC_EINVAL; }
+        } else
         if (kind != SSE_BOND_TRANSVERSE && sse_op_in(words[p]) != sse_op_out(words[p])) { b->err = "off-diagonal op on a diagonal-only bond (zero weight)"; return ISINGMC_EINVAL; }
         if (b->bonds_host[hoff + bond].c == SSE_NO_VAR && ((sse_op_in(words[p]) | sse_op_out(words[p])) & 2u)) { b->err = "single-site op with second-variable bits set"; return ISINGMC_EINVAL; }
         n++;

@@ -60,6 +60,7 @@ struct DevBatch {
     uint32_t seed_lo, seed_hi, replica_offset;
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
     uint32_t lds_words;   // dynamic LDS words available to the workgroup
+    const double *mats;   // generic interactions (Qmc, qmc_runner.rs:415-680): [Nb][16] weights indexed in | out<<2; NULL = Ising bonds
     uint32_t bond_stride; // 0, or Nb when every replica has its own bond table / cumulative weights (per-replica couplings)
     const double *wtot_r; // [R] per-replica total weight (bond_stride != 0)
     const uint32_t *adj_start, *adj; // [N+1], [2E] bonds_for_var (make_classical_bonds, qmc_ising.rs:421-432)
@@ -157,6 +158,13 @@ __device__ __forceinline__ double bond_weight(const Bd &b, uint32_t in, uint32_t
     const uint32_t sat = (kind == SSE_BOND_TWO_SITE) ? (uint32_t)(aligned == pref) : (uint32_t)((in & 1u) == pref);
     const bool ok = (kind == SSE_BOND_TRANSVERSE) | ((in == out) & (sat != 0u));
     return ok ? b.w : 0.0;
+}
+
+// matrix element of bond b for any model: Interaction::at (qmc_runner.rs:573-612) when the batch carries weight
+// matrices, the closed Ising form otherwise
+__device__ __forceinline__ double op_weight(const DevBatch &B, uint32_t b, const Bd &d, uint32_t in, uint32_t out) {
+    if (B.mats) return B.mats[(size_t)b * 16u + (in | (out << 2))];
+    return bond_weight(d, in, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -313,12 +321,15 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
     const uint32_t ntiles = (M + NT * K - 1) / (NT * K);
     int n_start = n_io, ntrans = 0;
 
-    // off-diagonal ops ("events") of a tile's words: variable and flag; Ising bonds: only single-site ops can be
-    // off-diagonal (bit 0 of in^out)
-    auto event_of = [&](uint32_t wd, uint32_t &var) -> bool {
-        const bool ev = ((sse_op_in(wd) ^ sse_op_out(wd)) & 1u) != 0u;
-        var = decode_bond<CL, W>(B, L, ev ? sse_op_bond(wd) : 0u).a;
-        return ev;
+    // off-diagonal ops ("events") of a tile's words: which of the op's variables flip.  Ising bonds: only single-site ops
+    // can be off-diagonal (bit 0 of in^out); generic two-variable interactions (never in CL mode) may flip either.
+    auto event_of = [&](uint32_t wd, uint32_t &va, uint32_t &vc, bool &fc) -> bool {
+        const uint32_t xb = sse_op_in(wd) ^ sse_op_out(wd);
+        const bool fa = (xb & 1u) != 0u;
+        fc = CL ? false : ((xb & 2u) != 0u);
+        const Bd d = decode_bond<CL, W>(B, L, (fa | fc) ? sse_op_bond(wd) : 0u);
+        va = d.a; vc = (!CL && d.c != SSE_NO_VAR) ? d.c : d.a;
+        return fa;
     };
     // flip the spin of the event variables in the tables of waves [wlo, whi) (wave-uniform bounds)
     auto propagate = [&](const uint32_t (&var)[K], const bool (&ev)[K], int wlo, int whi) {
@@ -339,10 +350,11 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
 #pragma unroll
     for (int j = 0; j < K; ++j) wnext[j] = ops[slot_of<W, K>(0, wave, j, lane)];
     {
-        uint32_t var[K]; bool ev[K];
+        uint32_t var[K], var2[K]; bool ev[K], ev2[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) ev[j] = event_of(wnext[j], var[j]);
+        for (int j = 0; j < K; ++j) ev[j] = event_of(wnext[j], var[j], var2[j], ev2[j]);
         propagate(var, ev, wave + 1, W);
+        if constexpr (!CL) propagate(var2, ev2, wave + 1, W);
     }
     __syncthreads();
 
@@ -364,8 +376,8 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         //   cw     : the op word to store when the candidate is accepted (new diagonal op, or 0 for a removal);
         //   keep   : the word to store otherwise (what the slot holds now)
         double fa[K], fb[K];
-        uint32_t cb[K], cw[K], keep[K], evA[K];
-        bool isevj[K];
+        uint32_t cb[K], cw[K], keep[K], evA[K], evC[K];
+        bool isevj[K], isevc[K];
         uint64_t insm[K]; // insert candidates
         uint32_t trbits = 0; // bit j: the op at stake in sub-round j is a transverse-field op
         uint4 rnd = make_uint4(0, 0, 0, 0);
@@ -374,8 +386,11 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
             const uint32_t wd = word[j];
             const bool occ = wd != 0u;
-            const uint32_t inb = sse_op_in(wd) & 1u;
-            const bool isev = ((sse_op_in(wd) ^ sse_op_out(wd)) & 1u) != 0u;
+            const uint32_t inb = sse_op_in(wd) & 1u, inc = (sse_op_in(wd) >> 1) & 1u;
+            const uint32_t xbits = sse_op_in(wd) ^ sse_op_out(wd);
+            const bool flipa = (xbits & 1u) != 0u;                        // the op flips its first variable
+            const bool flipc = CL ? false : ((xbits & 2u) != 0u);          // ... its second (generic interactions only)
+            const bool isev = flipa | flipc;
             const bool is_empty = (p < M) & !occ;
             const bool is_diag = occ & !isev;
             uint32_t r0, r1, r2 = 0;
@@ -424,7 +439,8 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 wbond = d.w;
                 nbond = beta_nb * d.w;
             }
-            evA[j] = va; isevj[j] = isev;
+            const bool generic = !CL && B.mats != nullptr; // wave-uniform
+            evA[j] = va; isevj[j] = flipa; evC[j] = vc; isevc[j] = flipc;
             trbits |= tr ? (1u << j) : 0u;
             // Spins at this slot = table value, corrected for the off-diagonal ops at EARLIER lanes of this
             // sub-round.  The op word itself carries the spin before (in) and after (out), so the event lanes
@@ -432,31 +448,38 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             // events on one variable inside a sub-round are rare; a serial loop over the event lanes handles them.
             const uint64_t ev0 = SSE_DBG(B, 16u) ? 0ull : sse_ballot(isev);
             if (ev0) {
-                if (isev) LDSH(L.o_cur, h_my + va) = (uint16_t)((((uint32_t)lane + 1u) << 1) | inb);
+                if (flipa) LDSH(L.o_cur, h_my + va) = (uint16_t)((((uint32_t)lane + 1u) << 1) | inb);
+                if (flipc) LDSH(L.o_cur, h_my + vc) = (uint16_t)((((uint32_t)lane + 1u) << 1) | inc);
                 SSE_WAVE_FENCE();
             }
             const uint32_t ea = LDSH(L.o_cur, h_my + va), ec = LDSH(L.o_cur, h_my + vc);
             uint32_t sa = ea & 1u, sc = ec & 1u;
             if (ev0) {
                 const uint32_t La = ea >> 1, Lc = ec >> 1;
-                const uint64_t dup = sse_ballot(isev & (La != (uint32_t)lane + 1u));
+                const uint64_t dup = sse_ballot((flipa & (La != (uint32_t)lane + 1u)) | (flipc & (Lc != (uint32_t)lane + 1u)));
                 if (!dup) {
                     sa ^= (uint32_t)((La - 1u) < (uint32_t)lane); // La == 0: no event on the variable
                     sc ^= (uint32_t)((Lc - 1u) < (uint32_t)lane);
                     SSE_WAVE_FENCE();
-                    if (isev) LDSH(L.o_cur, h_my + va) = (uint16_t)(inb ^ 1u);
+                    if (flipa) LDSH(L.o_cur, h_my + va) = (uint16_t)(inb ^ 1u);
+                    if (flipc) LDSH(L.o_cur, h_my + vc) = (uint16_t)(inc ^ 1u);
                 } else {
                     bool seen_a = false, seen_c = false;
                     uint64_t m = ev0;
                     while (m) {
                         const int Ls = __ffsll((long long)m) - 1;
                         m &= m - 1;
-                        const uint32_t vL = __builtin_amdgcn_readlane(va, Ls);
-                        const uint32_t inL = __builtin_amdgcn_readlane(inb, Ls);
                         const bool later = lane > Ls;
-                        if (va == vL) { sa = later ? (inL ^ 1u) : (seen_a ? sa : inL); seen_a = true; }
-                        if (vc == vL) { sc = later ? (inL ^ 1u) : (seen_c ? sc : inL); seen_c = true; }
-                        if (lane == Ls) LDSH(L.o_cur, h_my + va) = (uint16_t)(inL ^ 1u); // in order: the last event wins
+                        // up to two flipped variables per event lane (different variables of one op: order irrelevant)
+                        for (int which = 0; which < (CL ? 1 : 2); ++which) {
+                            const uint32_t fL = __builtin_amdgcn_readlane(which ? (uint32_t)flipc : (uint32_t)flipa, Ls);
+                            if (!fL) continue; // wave-uniform
+                            const uint32_t vL = __builtin_amdgcn_readlane(which ? vc : va, Ls);
+                            const uint32_t inL = __builtin_amdgcn_readlane(which ? inc : inb, Ls);
+                            if (va == vL) { sa = later ? (inL ^ 1u) : (seen_a ? sa : inL); seen_a = true; }
+                            if (vc == vL) { sc = later ? (inL ^ 1u) : (seen_c ? sc : inL); seen_c = true; }
+                            if (lane == Ls) LDSH(L.o_cur, h_my + vL) = (uint16_t)(inL ^ 1u); // in order: the last event wins
+                        }
                     }
                     SSE_WAVE_FENCE();
                 }
@@ -467,12 +490,21 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             // An op already in the string has its bond's weight (it was inserted with non-zero weight and the string
             // is consistent).
             const uint32_t agree = two ? ((sa ^ sc) ^ 1u) : sa;
-            const bool ok = tr | (agree == pref);
+            bool ok = tr | (agree == pref);
+            double w_gen = 0.0;
+            if constexpr (!CL) if (generic) {
+                // Interaction::at (qmc_runner.rs:573-612): the weight of the op at stake — the diagonal op that would be
+                // inserted (state sub) or the diagonal op in the slot (its own bits)
+                const uint32_t st = is_empty ? sub : sse_op_in(wd);
+                w_gen = B.mats[(size_t)b * 16u + (st | (st << 2))];
+                nbond = beta_nb * w_gen;
+                ok = true;
+            }
             const double uacc = u01(HB ? r0 : r1);
             bool ins;
             if (HB) {
                 // insert: u*(den + bW) < bW after the bond was chosen and kept with u1*maxw < w (heatbath.rs:163-193)
-                const double w_ins = ok ? wbond : 0.0;
+                const double w_ins = generic ? w_gen : (ok ? wbond : 0.0);
                 ins = is_empty & (u01(r1) * wbond < w_ins);
                 fa[j] = (ins | is_diag) ? uacc : inf;
                 fb[j] = 0.0;
@@ -525,11 +557,13 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 // events of this tile -> tables of earlier waves (all readers of this tile are done);
                 // events of the next tile -> tables of later waves (visible after the next barrier)
                 propagate(evA, isevj, 0, wave);
+                if constexpr (!CL) propagate(evC, isevc, 0, wave);
                 if (tile + 1 < ntiles) {
-                    uint32_t var[K]; bool ev[K];
+                    uint32_t var[K], var2[K]; bool ev[K], ev2[K];
 #pragma unroll
-                    for (int j = 0; j < K; ++j) ev[j] = event_of(wnext[j], var[j]);
+                    for (int j = 0; j < K; ++j) ev[j] = event_of(wnext[j], var[j], var2[j], ev2[j]);
                     propagate(var, ev, wave + 1, W);
+                    if constexpr (!CL) propagate(var2, ev2, wave + 1, W);
                 }
             }
             // every lane reads the same words: move them to scalar registers so that the loop stays wave-uniform
@@ -1169,7 +1203,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
             for (uint32_t leg = 0; leg < 2u * k; ++leg) {
                 uint32_t i2 = in_e, o2 = out_e;
                 if (leg < k) i2 ^= 1u << leg; else o2 ^= 1u << (leg - k);
-                wl[leg] = bond_weight(d, i2, o2);
+                wl[leg] = op_weight(B, sse_op_bond(word), d, i2, o2);
                 total += wl[leg];
             }
             const uint4 o = rng.draw(SSE_TAG_LOOP, step);

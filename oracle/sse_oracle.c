@@ -81,15 +81,50 @@ ora_model *ora_model_create(uint32_t nvars, uint32_t nedges, const uint32_t *edg
     m->wtot = c;
     return m;
 }
+/* Generic interactions (Qmc, qmc_runner.rs:94-156 make_interaction*, Interaction :415-680): bond b acts on k[b] = 1 or 2
+ * variables with an arbitrary non-negative weight matrix, given here already in the op-word layout
+ * mats[b][in | out << 2] (bit 0 = first variable, bit 1 = second).  Bond kinds only feed the transverse-op counters:
+ * a one-variable bond whose four entries are equal is a cluster edge (is_valid_cluster_edge, cluster.rs:284-286). */
+ora_model *ora_model_create_generic(uint32_t nvars, uint32_t nbonds, const uint32_t *k, const uint32_t *var_a,
+                                    const uint32_t *var_b, const double *mats, double offset) {
+    ora_model *m = (ora_model *)calloc(1, sizeof(*m));
+    m->nvars = nvars;
+    m->nedges = 0;
+    m->nbonds = nbonds;
+    m->bond_a = (uint32_t *)malloc(sizeof(uint32_t) * nbonds);
+    m->bond_b = (uint32_t *)malloc(sizeof(uint32_t) * nbonds);
+    m->binfo = (uint32_t *)malloc(sizeof(uint32_t) * nbonds);
+    m->bweight = (double *)malloc(sizeof(double) * nbonds);
+    m->cumw = (double *)malloc(sizeof(double) * nbonds);
+    m->mats = (double *)malloc(sizeof(double) * 16 * nbonds);
+    memcpy(m->mats, mats, sizeof(double) * 16 * nbonds);
+    double c = 0.0;
+    for (uint32_t b = 0; b < nbonds; ++b) {
+        const double *mb = mats + 16 * (size_t)b;
+        m->bond_a[b] = var_a[b];
+        m->bond_b[b] = k[b] == 2 ? var_b[b] : SSE_NO_VAR;
+        double maxw = 0.0; /* largest diagonal element (heatbath.rs:130-146 make_bond_weights) */
+        for (uint32_t s = 0; s < (k[b] == 2 ? 4u : 2u); ++s) if (mb[s | (s << 2)] > maxw) maxw = mb[s | (s << 2)];
+        m->bweight[b] = maxw;
+        if (k[b] == 2) m->binfo[b] = SSE_BOND_TWO_SITE;
+        else m->binfo[b] = (mb[0] == mb[1] && mb[0] == mb[4] && mb[0] == mb[5]) ? SSE_BOND_TRANSVERSE : SSE_BOND_LONGITUDINAL;
+        c = (b == 0) ? maxw : maxw + c;
+        m->cumw[b] = c;
+    }
+    m->wtot = c;
+    m->offset = offset;
+    return m;
+}
 void ora_model_destroy(ora_model *m) {
     if (!m) return;
-    free(m->bond_a); free(m->bond_b); free(m->binfo); free(m->bweight); free(m->cumw); free(m);
+    free(m->bond_a); free(m->bond_b); free(m->binfo); free(m->bweight); free(m->cumw); free(m->mats); free(m);
 }
 uint32_t ora_model_nbonds(const ora_model *m) { return m->nbonds; }
 double ora_model_offset(const ora_model *m) { return m->offset; }
 
 /* matrix element <out|H_b|in> of the shifted bond operator (qmc_ising.rs:863-888) */
 double ora_bond_weight(const ora_model *m, uint32_t b, uint32_t in, uint32_t out) {
+    if (m->mats) return m->mats[16 * (size_t)b + (in | (out << 2))]; /* Interaction::at (qmc_runner.rs:573-612) */
     uint32_t info = m->binfo[b];
     uint32_t pref = (info & SSE_BOND_PREF_BIT) ? 1u : 0u;
     switch (info & SSE_BOND_KIND_MASK) {

@@ -35,6 +35,9 @@ void ora_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 
 ora_model *ora_model_create(uint32_t nvars, uint32_t nedges, const uint32_t *edge_a, const uint32_t *edge_b,
                             const double *J, double gamma, double h);
+/* generic 1- and 2-variable interactions (qmc_runner.rs:415-680); mats[b][in | out<<2] */
+ora_model *ora_model_create_generic(uint32_t nvars, uint32_t nbonds, const uint32_t *k, const uint32_t *var_a,
+                                    const uint32_t *var_b, const double *mats, double offset);
 void ora_model_destroy(ora_model *m);
 uint32_t ora_model_nbonds(const ora_model *m);
 double ora_model_offset(const ora_model *m);

@@ -12,6 +12,7 @@ struct ora_model {
     double *cumw; /* heat-bath cumulative max weights (heatbath.rs:16-35) */
     double wtot;
     double offset, gamma, h;
+    double *mats; /* generic interactions (qmc_runner.rs:415-680): [nbonds][16] weights indexed in | out<<2, else NULL */
 };
 
 struct ora_replica {

@@ -35,3 +35,49 @@ def cubic_periodic(l):
                 edges.append(((a, (z * l + (y + 1) % l) * l + x), 1.0))
                 edges.append(((a, (((z + 1) % l) * l + y) * l + x), 1.0))
     return edges
+
+
+def xxz_ring_interactions(n, t=1.0, jz=0.5, c=1.0, hx=0.3):
+    """Generic-interaction test model on a ring of n sites (weights = matrix elements of -H_b + const, all >= 0):
+    two-site bonds with hopping t (|01> <-> |10>), Ising part jz (favouring aligned spins) and constant c on the diagonal;
+    one-site bonds hx*(sigma_x + 1).  Matrices in the reference's layout (index = out0 out1 in0 in1, qmc_runner.rs:666-679).
+    Returns [(mat, vars), ...]."""
+    import numpy as np
+    ints = []
+    for i in range(n):
+        m = np.zeros(16)
+        for s in range(4):  # s = (s0 s1), first variable most significant
+            aligned = ((s >> 1) & 1) == (s & 1)
+            m[(s << 2) | s] = c + (jz if aligned else 0.0)
+        m[(0b01 << 2) | 0b10] = t
+        m[(0b10 << 2) | 0b01] = t
+        ints.append((m, (i, (i + 1) % n)))
+    for i in range(n):
+        ints.append((np.full(4, hx), (i,)))
+    return ints
+
+
+def exact_energy_from_interactions(n, ints, beta):
+    """<H> at inverse temperature beta for H = -sum_b M_b (dense, n <= 10)."""
+    import numpy as np
+    dim = 1 << n
+    H = np.zeros((dim, dim))
+    for mat, vs in ints:
+        k = len(vs)
+        for s_in in range(dim):
+            bits_in = [(s_in >> (n - 1 - v)) & 1 for v in vs]
+            iin = 0
+            for bbit in bits_in:
+                iin = (iin << 1) | bbit
+            for iout in range(1 << k):
+                w = mat[(iout << k) | iin]
+                if w == 0.0:
+                    continue
+                s_out = s_in
+                for j, v in enumerate(vs):
+                    ob = (iout >> (k - 1 - j)) & 1
+                    s_out = (s_out & ~(1 << (n - 1 - v))) | (ob << (n - 1 - v))
+                H[s_out, s_in] -= w
+    ev = np.linalg.eigvalsh(H)
+    wts = np.exp(-beta * (ev - ev.min()))
+    return float((ev * wts).sum() / wts.sum())

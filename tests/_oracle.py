@@ -36,6 +36,8 @@ def load():
         "ora_loop_update": (u32, [vp]),
         "ora_timestep": (C.c_int, [vp, f64, u32]),
         "ora_timesteps": (C.c_int, [vp, u64, f64, u32, u32]),
+        "ora_model_create_generic": (vp, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_double), C.c_double]),
         "ora_verify": (C.c_int, [vp]),
         "ora_itime_magnetization": (None, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "ora_get_n": (u32, [vp]),
@@ -94,6 +96,34 @@ class Model:
                                           _ptr(self.J, C.c_double), self.gamma, self.h)
         self.nbonds = lib().ora_model_nbonds(self.ptr)
         self.offset = lib().ora_model_offset(self.ptr)
+
+    @classmethod
+    def generic(cls, nvars, interactions, offset=0.0):
+        """Arbitrary 1-/2-variable interactions [(mat, vars), ...] with the reference's matrix layout (index = outputs then
+        inputs, first variable most significant, qmc_runner.rs:666-679); converted here to the oracle's in | out<<2."""
+        self = cls.__new__(cls)
+        self.nvars = int(nvars)
+        nb = len(interactions)
+        ks = np.zeros(nb, dtype=np.uint32); va = np.zeros(nb, dtype=np.uint32); vb = np.zeros(nb, dtype=np.uint32)
+        mats = np.zeros((nb, 16), dtype=np.float64)
+        for i, (mat, vs) in enumerate(interactions):
+            mat = np.asarray(mat, dtype=np.float64)
+            ks[i] = len(vs); va[i] = vs[0]; vb[i] = vs[1] if len(vs) == 2 else 0
+            if len(vs) == 2:
+                for i_ in range(4):
+                    for o_ in range(4):
+                        ref = ((o_ & 1) << 3) | (((o_ >> 1) & 1) << 2) | ((i_ & 1) << 1) | ((i_ >> 1) & 1)
+                        mats[i, i_ | (o_ << 2)] = mat[ref]
+            else:
+                for i_ in range(2):
+                    for o_ in range(2):
+                        mats[i, i_ | (o_ << 2)] = mat[(o_ << 1) | i_]
+        self.gamma = self.h = 0.0
+        self.ptr = lib().ora_model_create_generic(self.nvars, nb, _ptr(ks, C.c_uint32), _ptr(va, C.c_uint32), _ptr(vb, C.c_uint32),
+                                                  _ptr(np.ascontiguousarray(mats), C.c_double), float(offset))
+        self.nbonds = nb
+        self.offset = float(offset)
+        return self
 
     def __del__(self):
         if getattr(self, "ptr", None):

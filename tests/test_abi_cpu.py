@@ -29,8 +29,8 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_config_struct_layout_matches_header():
     import isingmontecarlo_amd as im
-    # 4 u32, 2 pointers, 2 doubles, 2 u32, u64, u32, i32, pointer, 5 u32 (+4 padding) -> 104 bytes on LP64
-    assert C.sizeof(im._Config) == 104
+    # 4 u32, 2 pointers, 2 doubles, 2 u32, u64, u32, i32, pointer, 5 u32 (+4 padding), pointer, u32 (+4), double -> 128 bytes on LP64
+    assert C.sizeof(im._Config) == 128
     assert im._Config.seed.offset == 56 and im._Config.init_state.offset == 72
 
 
