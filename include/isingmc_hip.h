@@ -74,8 +74,9 @@ typedef struct isingmc_config {
                                  * per launch (16 while the scan tables and the union-find fit in LDS); 1, 4, 6, 8, 16 */
     /* Generic interactions (qmc::sse::Qmc, qmc_runner.rs:94-156, Interaction :415-680).  When `interactions` is non-NULL
      * the batch is built from them and edges / J / transverse / longitudinal are ignored: bond b = interaction b.
-     * Available updates: diagonal (Metropolis or heat-bath), directed loop, free spins; cluster and RVB updates are
-     * Ising-specific and return ISINGMC_ENOTIMPL. */
+     * Available updates: diagonal (Metropolis or heat-bath), directed loop, free spins, and cluster updates when every
+     * interaction is symmetric under a global spin flip (Qmc::cluster_update, qmc_runner.rs:222-236; one-variable
+     * interactions with four equal entries are the cluster edges).  RVB updates return ISINGMC_ENOTIMPL. */
     const struct isingmc_interaction *interactions;
     uint32_t ninteractions;
     double energy_offset;       /* added to -<n>/beta by isingmc_get_offset (sum of the offsets the caller absorbed,

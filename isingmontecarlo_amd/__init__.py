@@ -477,11 +477,13 @@ class Qmc(QmcIsingGraph):
 
     @classmethod
     def from_interactions(cls, nvars, interactions, cutoff, seed, energy_offset=0.0, state=None, nreplicas=1, capacity=None,
-                          replica_offset=0, device=-1, waves_per_replica=0, slots_per_lane=0, do_loop_updates=True):
+                          replica_offset=0, device=-1, waves_per_replica=0, slots_per_lane=0, do_loop_updates=True,
+                          do_cluster_updates=None):
         """qmc::sse::Qmc with arbitrary one- and two-variable interactions: `interactions` = [(mat, vars), ...] with
         mat the reference's 4^k weight matrix (index = outputs then inputs, first variable most significant) and all
-        entries >= 0.  timestep = diagonal update -> directed loop (if enabled) -> free spins; cluster and RVB updates
-        are Ising-specific and not available."""
+        entries >= 0.  timestep = diagonal update -> directed loop (if enabled) -> cluster update -> free spins
+        (qmc_runner.rs:363-377); the cluster update runs by default exactly when the reference's would: the model has
+        cluster edges (constant one-variable interactions) and does not break the Ising symmetry (:260-270)."""
         self = cls.__new__(cls)
         lib = load_library()
         self._lib, self._h = lib, None
@@ -522,7 +524,13 @@ class Qmc(QmcIsingGraph):
             raise IsingMcError(rc, lib.isingmc_last_error(None).decode())
         self._h = h
         self.capacity = int(capacity)
-        self._flags = FLAG_NO_CLUSTER | (FLAG_LOOP if do_loop_updates else 0)
+        if do_cluster_updates is None:
+            def sym(m, k):
+                m = np.asarray(m); size = 4 ** k
+                return all(abs(m[i] - m[(size - 1) ^ i]) < np.finfo(float).eps for i in range(size))
+            has_edges = any(len(v) == 1 and np.ptp(np.asarray(m)) < np.finfo(float).eps for m, v in interactions)
+            do_cluster_updates = has_edges and all(sym(m, len(v)) for m, v in interactions)
+        self._flags = (0 if do_cluster_updates else FLAG_NO_CLUSTER) | (FLAG_LOOP if do_loop_updates else 0)
         self._acc_rows = self.nreplicas
         return self
 

@@ -38,6 +38,7 @@ struct isingmc_batch {
     std::vector<double> offsets;        // per-replica energy offsets (ISINGMC_CFG_PER_REPLICA_J), else empty
     bool per_replica_J = false;
     bool generic = false;               // built from isingmc_interaction matrices
+    bool generic_sym = false;           // ... all of them symmetric under a global spin flip (cluster updates allowed)
     std::vector<double> mats_host;      // [Nb][16] in | out<<2
     std::vector<BondRec> bonds_host;
     double *d_beta = nullptr;
@@ -255,7 +256,8 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         b->err = "beta is required for a diagonal update";
         return ISINGMC_EINVAL;
     }
-    if ((domask & (SSE_DO_RVB | SSE_DO_CLUSTER)) && b->generic) { b->err = "cluster and RVB updates are Ising-specific: not available with generic interactions"; return ISINGMC_ENOTIMPL; }
+    if ((domask & SSE_DO_RVB) && b->generic) { b->err = "RVB updates are Ising-specific: not available with generic interactions"; return ISINGMC_ENOTIMPL; }
+    if ((domask & SSE_DO_CLUSTER) && b->generic && !b->generic_sym) { b->err = "Cannot perform cluster updates on graphs that break ising symmetry."; return ISINGMC_ENOTIMPL; } // qmc_runner.rs:224-226
     if ((domask & SSE_DO_RVB) && b->per_replica_J) { b->err = "RVB updates with per-replica couplings are not implemented"; return ISINGMC_ENOTIMPL; }
     A.sampling_freq = freq;
     A.domask = domask & 0xFFFFu;
@@ -454,6 +456,14 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         }
         wtots[0] = c;
         b->offset = cfg->energy_offset;
+        // Interaction::sym_under_ising (qmc_runner.rs:639-664): every weight equals the weight with all spins flipped
+        b->generic_sym = true;
+        for (uint32_t i = 0; i < D.Nb && b->generic_sym; ++i) {
+            const double *mb = b->mats_host.data() + (size_t)i * 16;
+            const uint32_t mask = cfg->interactions[i].nvars == 2 ? 0xFu : 0x5u;
+            for (uint32_t idx = 0; idx < 16; ++idx)
+                if ((idx & ~mask) == 0 && std::fabs(mb[idx] - mb[idx ^ mask]) >= DBL_EPSILON) { b->generic_sym = false; break; }
+        }
     }
     for (uint32_t hI = 0; !generic && hI < nH; ++hI) {
         BondRec *t0 = tab.data() + (size_t)hI * D.Nb;

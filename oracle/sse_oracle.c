@@ -327,10 +327,10 @@ uint32_t ora_cluster_update(ora_replica *r, double prob) {
             uint32_t c = m->bond_b[b];
             touched[c] = 1;
             uf_union(parent, cur[a], cur[c]);
-        } else {
+        } else if (!m->mats) { /* longitudinal-field op of the Ising model: its cluster never flips */
             frozen[cur[a]] = 1;
             any_long = 1;
-        }
+        } /* generic Ising-symmetric interactions (Qmc::cluster_update, qmc_runner.rs:222-236): an interior op */
     }
     const uint32_t S = N + ncuts;
     if (ncuts == 0) {

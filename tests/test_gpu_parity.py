@@ -383,8 +383,9 @@ def test_cpp_example_through_the_c_abi(tmp_path):
     assert abs(energy - exact) < 5 * sem + 1e-3, (energy, sem, exact)
 
 
+@pytest.mark.parametrize("cluster", [False, True])
 @pytest.mark.parametrize("waves,k,heatbath,loop", [(0, 0, False, True), (4, 4, True, True), (1, 1, False, True), (8, 2, False, False), (16, 4, True, False)])
-def test_generic_interactions_match_oracle(oracle, waves, k, heatbath, loop):
+def test_generic_interactions_match_oracle(oracle, waves, k, heatbath, loop, cluster):
     """qmc::sse::Qmc with arbitrary one- and two-variable weight matrices (qmc_runner.rs:415-680): XXZ ring with hopping
     (two-variable off-diagonal ops) plus constant one-variable terms; diagonal (Metropolis / heat-bath) + directed loop +
     free spins against the oracle, bit for bit."""
@@ -392,10 +393,10 @@ def test_generic_interactions_match_oracle(oracle, waves, k, heatbath, loop):
     n, R, beta, cutoff, cap, seed = 7, 5, 1.5, 8, 1 << 12, 909
     ints = lat.xxz_ring_interactions(n)
     g = im.Qmc.from_interactions(n, ints, cutoff, seed, nreplicas=R, capacity=cap, waves_per_replica=waves, slots_per_lane=k,
-                                 do_loop_updates=loop)
+                                 do_loop_updates=loop, do_cluster_updates=cluster)
     m = oracle.Model.generic(n, ints)
     reps = [oracle.Replica(m, cap, cutoff, seed, r, None) for r in range(R)]
-    flags = im.FLAG_NO_CLUSTER | (im.FLAG_LOOP if loop else 0) | (im.FLAG_HEATBATH if heatbath else 0)
+    flags = (0 if cluster else im.FLAG_NO_CLUSTER) | (im.FLAG_LOOP if loop else 0) | (im.FLAG_HEATBATH if heatbath else 0)
     g.run(60, beta, sampling_freq=2, flags=flags)
     for rep in reps:
         rep.timesteps(60, beta, 2, flags)
@@ -406,5 +407,7 @@ def test_generic_interactions_match_oracle(oracle, waves, k, heatbath, loop):
     assert g.verify().all()
     if loop:  # two-variable off-diagonal ops (hopping) are really there
         assert any(((int(w) >> 4) - 1) < n and (int(w) & 3) != ((int(w) >> 2) & 3) for r in range(R) for w in g.export_ops(r) if w)
+    # a model that breaks the Ising symmetry refuses cluster updates like the reference (qmc_runner.rs:224-226)
+    broken = im.Qmc.from_interactions(2, [(np.array([1.0, 0, 0, 2.0]), (0,)), (np.full(4, 0.5), (1,))], 4, 1)
     with pytest.raises(im.IsingMcError):
-        g.single_cluster_step()
+        broken.single_cluster_step()
