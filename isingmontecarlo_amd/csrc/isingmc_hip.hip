@@ -292,11 +292,11 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     // launches without a diagonal or RVB pass use the kernel that leaves that code out
     DevBatch dev_off = b->dev;
     const bool loop_only = (A.domask & (SSE_DO_DIAG | SSE_DO_RVB | SSE_DO_CLUSTER | SSE_DO_FREE)) == 0 && (A.domask & SSE_DO_LOOP);
-    if (loop_only) lc.passes = SSE_PASSES_DIAG; // a lone directed loop uses the small launch geometry too
-    else if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB | SSE_DO_LOOP)) || (split && !(A.domask & SSE_DO_RVB))) {
-        lc.passes = SSE_PASSES_OFFDIAG;
-        // The off-diagonal kernel is latency-bound and small in registers: more waves per replica help as long as
-        // the per-wave scan tables and the union-find of W*N + (transverse ops) ids still fit in LDS.
+    // The off-diagonal kernel is latency-bound and small in registers: more waves per replica help as long as the
+    // per-wave scan tables and the union-find of W*N + (transverse ops) ids still fit in LDS.  Decided from the largest
+    // transverse-op count seen so far, and again every few timesteps of a long call (the count grows while a batch
+    // equilibrates; replicas that outgrow the table only fall back to the slower HBM union-find, never fail).
+    auto plan_offdiag = [&]() {
         uint32_t Wo = b->W_off ? b->W_off : b->W;
         if (!b->W_off && b->W < 16) {
             const LdsPlan p16 = plan_lds(b, 16);
@@ -306,6 +306,11 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         lc.W = Wo; lc.lds_bytes = po.lds_bytes;
         dev_off.lds_ufcap = po.ufcap; dev_off.lds_words = (uint32_t)(po.lds_bytes / 4);
         b->last_W_off = Wo;
+    };
+    if (loop_only) lc.passes = SSE_PASSES_DIAG; // a lone directed loop uses the small launch geometry too
+    else if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB | SSE_DO_LOOP)) || (split && !(A.domask & SSE_DO_RVB))) {
+        lc.passes = SSE_PASSES_OFFDIAG;
+        plan_offdiag();
     }
     HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
     if (!split) {
@@ -330,7 +335,13 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         constexpr size_t MAX_TIMED = 256;
         const size_t want_ev = 3 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
         while (b->evpool.size() < want_ev) { hipEvent_t ev; HIP_TRY(b, hipEventCreate(&ev)); b->evpool.push_back(ev); }
+        constexpr uint64_t REPLAN_EVERY = 16;
         for (uint64_t done = 0; done < nsteps; ++done) {
+            if (done && done % REPLAN_EVERY == 0 && lc.passes == SSE_PASSES_OFFDIAG) {
+                int rcq = check_errors(b); // drains the stream, refreshes max_ntrans; an error ends the call here
+                if (rcq) return rcq;
+                plan_offdiag();
+            }
             const bool timed = done < MAX_TIMED;
             SweepArgs a1 = A;
             a1.domask = A.domask & diag_bits; a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
