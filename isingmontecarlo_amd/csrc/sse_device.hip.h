@@ -327,8 +327,14 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         const uint32_t xb = sse_op_in(wd) ^ sse_op_out(wd);
         const bool fa = (xb & 1u) != 0u;
         fc = CL ? false : ((xb & 2u) != 0u);
-        const Bd d = decode_bond<CL, W>(B, L, (fa | fc) ? sse_op_bond(wd) : 0u);
-        va = d.a; vc = (!CL && d.c != SSE_NO_VAR) ? d.c : d.a;
+        if constexpr (CL) { // only one-variable ops flip a spin here: their variable follows from the bond number alone
+            const uint32_t s1 = sse_op_bond(wd) - B.E;
+            va = fa ? (s1 < B.N ? s1 : s1 - B.N) : 0u;
+            vc = va;
+        } else {
+            const Bd d = decode_bond<CL, W>(B, L, (fa | fc) ? sse_op_bond(wd) : 0u);
+            va = d.a; vc = d.c != SSE_NO_VAR ? d.c : d.a;
+        }
         return fa;
     };
     // flip the spin of the event variables in the tables of waves [wlo, whi) (wave-uniform bounds)
