@@ -339,11 +339,23 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
     };
     // flip the spin of the event variables in the tables of waves [wlo, whi) (wave-uniform bounds)
     auto propagate = [&](const uint32_t (&var)[K], const bool (&ev)[K], int wlo, int whi) {
-        for (int w2 = wlo; w2 < whi; ++w2) {
-            const uint32_t base = (uint32_t)w2 * N;
+        if ((N & 1u) == 0u) { // tables start on word boundaries: word index and bit inside a table do not depend on the wave
+            uint32_t widx[K], bit[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j)
-                if (ev[j]) spin_table_flip(L.o_cur, base + var[j]);
+            for (int j = 0; j < K; ++j) { widx[j] = var[j] >> 1; bit[j] = 1u << ((var[j] & 1u) * 16u); }
+            for (int w2 = wlo; w2 < whi; ++w2) {
+                const uint32_t tbl = L.o_cur + (uint32_t)w2 * (N >> 1);
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    if (ev[j]) atomicXor(&LDSW(tbl, widx[j]), bit[j]);
+            }
+        } else {
+            for (int w2 = wlo; w2 < whi; ++w2) {
+                const uint32_t base = (uint32_t)w2 * N;
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    if (ev[j]) spin_table_flip(L.o_cur, base + var[j]);
+            }
         }
     };
 
