@@ -12,8 +12,6 @@ HEADERS = ["sse_device.hip.h", os.path.join("..", "..", "include", "isingmc_hip.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 if os.environ.get("SSE_MIN_WAVES"):  # experiment: force the register budget for N waves per SIMD (W = 8 kernels)
     FLAGS.append("-DSSE_MIN_WAVES_PER_SIMD=" + os.environ["SSE_MIN_WAVES"])
-if os.environ.get("SSE_EXPERIMENT"):  # timing experiments only (results are wrong)
-    FLAGS.append("-D" + os.environ["SSE_EXPERIMENT"])
 if os.environ.get("SSE_PHASE_TIMING"):  # diagnostic build: in-kernel phase stamps (never benchmarked)
     FLAGS.append("-DSSE_PHASE_TIMING")
 
