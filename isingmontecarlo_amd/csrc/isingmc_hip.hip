@@ -330,7 +330,8 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         LaunchCfg ld = lc;
         ld.W = b->W;
         ld.passes = SSE_PASSES_DIAG;
-        ld.lds_bytes = (4 * b->lds_fixed_words_ + 7) & ~(size_t)7;
+        // the diagonal launch needs the fixed regions up to the per-wave tables, which it uses as [W][N] bytes
+        ld.lds_bytes = (4 * (b->lds_fixed_words_ - ((size_t)b->W * b->dev.N + 1) / 2) + 7) & ~(size_t)7;
         const uint32_t rest = A.domask & ~diag_bits;
         constexpr size_t MAX_TIMED = 256;
         const size_t want_ev = 3 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
@@ -961,7 +962,7 @@ int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->CL; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8); out[7] = (uint32_t)((4 * b->lds_fixed_words_ + 7) & ~(size_t)7);
+    out[4] = b->K; out[5] = b->CL; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8); out[7] = (uint32_t)((4 * (b->lds_fixed_words_ - ((size_t)b->W * b->dev.N + 1) / 2) + 7) & ~(size_t)7);
     return ISINGMC_OK;
 }
 

@@ -261,8 +261,8 @@ __device__ __forceinline__ bool sse_any(bool p) { return __builtin_amdgcn_ballot
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 
-// flip bit 0 of 16-bit element e of the table at word offset off (other waves' tables: 32-bit atomic on the word)
-__device__ __forceinline__ void spin_table_flip(uint32_t off, uint32_t e) { atomicXor(&LDSW(off, e >> 1), 1u << ((e & 1u) * 16u)); }
+// flip bit 0 of 8-bit element e of the table at word offset off (other waves' tables: 32-bit atomic on the word)
+__device__ __forceinline__ void spin_table_flip(uint32_t off, uint32_t e) { atomicXor(&LDSW(off, e >> 2), 1u << ((e & 3u) * 8u)); }
 
 // A wave-uniform double pinned into vector registers: selects between such values then cost two v_cndmask each,
 // instead of copying scalar halves into vector registers at every use.
@@ -309,12 +309,12 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         wJv = vgpr_copy(B.wJ); wGv = vgpr_copy(B.gamma); wHv = vgpr_copy(B.wh);
         nJv = vgpr_copy(beta_nb * B.wJ); nGv = vgpr_copy(beta_nb * B.gamma); nHv = vgpr_copy(beta_nb * B.wh);
     }
-    // Per-wave spin tables T_w[v] (u16, in the o_cur area the cluster scan uses later): bit 0 = spin of v at the
-    // wave's current position; bits 1.. = lane+1 of an off-diagonal op on v inside the sub-round being resolved.
+    // Per-wave spin tables T_w[v] (u8, in the o_cur area the cluster scan uses later): bit 0 = spin of v at the
+    // wave's current position; bits 1..7 = lane+1 of an off-diagonal op on v inside the sub-round being resolved.
     const uint32_t N = B.N, h_my = (uint32_t)wave * N;
     for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) {
         const uint32_t v = i % N;
-        LDSH(L.o_cur, i) = (uint16_t)((LDSW(L.o_state, v >> 5) >> (v & 31)) & 1u);
+        LDSB(L.o_cur, i) = (uint8_t)((LDSW(L.o_state, v >> 5) >> (v & 31)) & 1u);
     }
     __syncthreads();
 
@@ -339,12 +339,12 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
     };
     // flip the spin of the event variables in the tables of waves [wlo, whi) (wave-uniform bounds)
     auto propagate = [&](const uint32_t (&var)[K], const bool (&ev)[K], int wlo, int whi) {
-        if ((N & 1u) == 0u) { // tables start on word boundaries: word index and bit inside a table do not depend on the wave
+        if ((N & 3u) == 0u) { // tables start on word boundaries: word index and bit inside a table do not depend on the wave
             uint32_t widx[K], bit[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) { widx[j] = var[j] >> 1; bit[j] = 1u << ((var[j] & 1u) * 16u); }
+            for (int j = 0; j < K; ++j) { widx[j] = var[j] >> 2; bit[j] = 1u << ((var[j] & 3u) * 8u); }
             for (int w2 = wlo; w2 < whi; ++w2) {
-                const uint32_t tbl = L.o_cur + (uint32_t)w2 * (N >> 1);
+                const uint32_t tbl = L.o_cur + (uint32_t)w2 * (N >> 2);
 #pragma unroll
                 for (int j = 0; j < K; ++j)
                     if (ev[j]) atomicXor(&LDSW(tbl, widx[j]), bit[j]);
@@ -466,11 +466,11 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             // events on one variable inside a sub-round are rare; a serial loop over the event lanes handles them.
             const uint64_t ev0 = SSE_DBG(B, 16u) ? 0ull : sse_ballot(isev);
             if (ev0) {
-                if (flipa) LDSH(L.o_cur, h_my + va) = (uint16_t)((((uint32_t)lane + 1u) << 1) | inb);
-                if (flipc) LDSH(L.o_cur, h_my + vc) = (uint16_t)((((uint32_t)lane + 1u) << 1) | inc);
+                if (flipa) LDSB(L.o_cur, h_my + va) = (uint8_t)((((uint32_t)lane + 1u) << 1) | inb);
+                if (flipc) LDSB(L.o_cur, h_my + vc) = (uint8_t)((((uint32_t)lane + 1u) << 1) | inc);
                 SSE_WAVE_FENCE();
             }
-            const uint32_t ea = LDSH(L.o_cur, h_my + va), ec = LDSH(L.o_cur, h_my + vc);
+            const uint32_t ea = LDSB(L.o_cur, h_my + va), ec = LDSB(L.o_cur, h_my + vc);
             uint32_t sa = ea & 1u, sc = ec & 1u;
             if (ev0) {
                 const uint32_t La = ea >> 1, Lc = ec >> 1;
@@ -479,8 +479,8 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                     sa ^= (uint32_t)((La - 1u) < (uint32_t)lane); // La == 0: no event on the variable
                     sc ^= (uint32_t)((Lc - 1u) < (uint32_t)lane);
                     SSE_WAVE_FENCE();
-                    if (flipa) LDSH(L.o_cur, h_my + va) = (uint16_t)(inb ^ 1u);
-                    if (flipc) LDSH(L.o_cur, h_my + vc) = (uint16_t)(inc ^ 1u);
+                    if (flipa) LDSB(L.o_cur, h_my + va) = (uint8_t)(inb ^ 1u);
+                    if (flipc) LDSB(L.o_cur, h_my + vc) = (uint8_t)(inc ^ 1u);
                 } else {
                     bool seen_a = false, seen_c = false;
                     uint64_t m = ev0;
@@ -496,7 +496,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                             const uint32_t inL = __builtin_amdgcn_readlane(which ? inc : inb, Ls);
                             if (va == vL) { sa = later ? (inL ^ 1u) : (seen_a ? sa : inL); seen_a = true; }
                             if (vc == vL) { sc = later ? (inL ^ 1u) : (seen_c ? sc : inL); seen_c = true; }
-                            if (lane == Ls) LDSH(L.o_cur, h_my + vL) = (uint16_t)(inL ^ 1u); // in order: the last event wins
+                            if (lane == Ls) LDSB(L.o_cur, h_my + vL) = (uint8_t)(inL ^ 1u); // in order: the last event wins
                         }
                     }
                     SSE_WAVE_FENCE();
