@@ -273,6 +273,16 @@ __device__ __forceinline__ double vgpr_copy(double x) {
     return __hiloint2double(vhi, vlo);
 }
 
+// Row accesses as (uniform base pointer) + (32-bit byte offset): the offset is computed in 32 bits (rows are far below
+// 2^30 words), which lets the compiler use the scalar-base + vector-offset addressing mode instead of 64-bit vector
+// address arithmetic per access.
+__device__ __forceinline__ uint32_t row_ld(const uint32_t *row, uint32_t idx) {
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(row) + (size_t)(idx * 4u));
+}
+__device__ __forceinline__ void row_st(uint32_t *row, uint32_t idx, uint32_t v) {
+    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(row) + (size_t)(idx * 4u)) = v;
+}
+
 // slot index of (tile, wave, sub-round j, lane)
 template <int W, int K>
 __device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int lane) {
@@ -366,7 +376,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
     uint32_t wnext[K];
     // prologue: tile 0 words; their events go to the tables of later waves
 #pragma unroll
-    for (int j = 0; j < K; ++j) wnext[j] = ops[slot_of<W, K>(0, wave, j, lane)];
+    for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, slot_of<W, K>(0, wave, j, lane));
     {
         uint32_t var[K], var2[K]; bool ev[K], ev2[K];
 #pragma unroll
@@ -385,7 +395,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         {   // prefetch the next tile (after the last one: the same tile again, the values are not used)
             const uint32_t tn = tile + 1 < ntiles ? tile + 1 : tile;
 #pragma unroll
-            for (int j = 0; j < K; ++j) wnext[j] = ops[slot_of<W, K>(tn, wave, j, lane)];
+            for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, slot_of<W, K>(tn, wave, j, lane));
         }
 
         // per slot, kept across the rounds:
@@ -618,7 +628,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         int dn = 0, dtr = 0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            ops[slot_of<W, K>(tile, wave, j, lane)] = ((acc[j] >> lane) & 1ull) ? cw[j] : keep[j];
+            row_st(ops, slot_of<W, K>(tile, wave, j, lane), ((acc[j] >> lane) & 1ull) ? cw[j] : keep[j]);
             const uint64_t im = acc[j] & insm[j], rm = acc[j] & ~insm[j];
             const uint64_t trm = sse_ballot((trbits >> j) & 1u);
             dn += popc64(im) - popc64(rm);
@@ -741,6 +751,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t N = B.N;
     uint32_t *ops = B.ops + (size_t)r * B.stride;
+    uint32_t *segs_row = B.segs + (size_t)r * B.stride;
     const uint32_t h_mycur = (uint32_t)wave * N; // element offset of this wave's tables inside o_cur / o_cl
     for (uint32_t i = tid; i < ((uint32_t)W * N + 1) / 2; i += NT) LDSW(L.o_cur, i) = 0u;
     for (uint32_t i = tid; i < ((uint32_t)W * N + 3) / 4; i += NT) LDSW(L.o_cl, i) = 0u;
@@ -762,7 +773,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
     // padded row holds zeros; past the range end the last tile is simply read again
     uint32_t wnext[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) wnext[j] = ops[pbeg + j * 64 + lane];
+    for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, pbeg + j * 64 + lane);
     for (uint32_t p0 = pbeg; p0 < pend; p0 += TS) {
         uint32_t word[K];
 #pragma unroll
@@ -770,7 +781,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
         {
             const uint32_t pn0 = p0 + TS < pend ? p0 + TS : p0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) wnext[j] = ops[pn0 + j * 64 + lane];
+            for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, pn0 + j * 64 + lane);
         }
         uint32_t ua[K], uc[K]; // the tile's unions, issued together after the K sub-rounds (unions commute)
         bool utwo[K];
@@ -784,7 +795,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             const bool two = nonempty & (d.c != SSE_NO_VAR);
             const uint32_t vc = two ? d.c : va;
             const bool iscut = nonempty & (kind == SSE_BOND_TRANSVERSE);
-            const uint64_t cutmask = sse_ballot(iscut);
+            const uint64_t cutmask = sse_ballot(nonempty) & sse_ballot(kind == SSE_BOND_TRANSVERSE); // = ballot(iscut), from the compare masks
             const uint32_t first = idbase + nlocal + 1u;
             const uint32_t kown = popc64(cutmask & lanemask_lt(lane)); // cuts of this sub-round at earlier lanes
             const uint32_t id_own = first + kown;
@@ -804,7 +815,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             uint32_t seg_c = xc ? idbase + xc : my_placeholder_base + vc;
             if (cutmask) {
                 const uint32_t myrank1 = id_own - idbase; // rank+1 of this lane's cut inside the wave's range
-                const uint64_t dup = sse_ballot(iscut & (ma != kown + 1u));
+                const uint64_t dup = cutmask & sse_ballot(ma != kown + 1u);
                 if (!dup) {
                     seg_a = ((ma - 1u) < kown) ? first + (ma - 1u) : seg_a; // ma == 0: no cut on the variable
                     seg_c = ((mc - 1u) < kown) ? first + (mc - 1u) : seg_c;
@@ -838,7 +849,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                 if (B.has_long) if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
                 if constexpr (!G) { // ids fit 16 bits on this path: remember them for the apply pass
                     const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
-                    B.segs[(size_t)r * B.stride + p0 + j * 64 + lane] = seg_a | (hi << 16);
+                    row_st(segs_row, p0 + j * 64 + lane, seg_a | (hi << 16));
                 }
             } else {
                 const uint32_t fa = uf.get(seg_a), fc = uf.get(seg_c), fo = uf.get(iscut ? id_own : seg_a);
@@ -908,7 +919,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
     constexpr uint32_t TS = (uint32_t)(K * NT);
     uint32_t wn[K], sn[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) { wn[j] = ops[(uint32_t)(j * NT + tid)]; sn[j] = segs[(uint32_t)(j * NT + tid)]; }
+    for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, (uint32_t)(j * NT + tid)); }
     for (uint32_t p0 = 0; p0 < M; p0 += TS) {
         uint32_t wd[K], sg[K];
 #pragma unroll
@@ -916,7 +927,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
         {
             const uint32_t pn0 = p0 + TS < M ? p0 + TS : p0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) { wn[j] = ops[pn0 + (uint32_t)(j * NT + tid)]; sn[j] = segs[pn0 + (uint32_t)(j * NT + tid)]; }
+            for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, pn0 + (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, pn0 + (uint32_t)(j * NT + tid)); }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -932,7 +943,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
             const uint32_t in = sse_op_in(w) ^ (two ? (fa | (fb << 1)) : fa);
             const uint32_t out = sse_op_out(w) ^ (two ? (fa | (fb << 1)) : fb);
             const uint32_t neww = (w & ~0xFu) | in | (out << SSE_OP_OUT_SHIFT);
-            ops[p0 + (uint32_t)(j * NT + tid)] = nonempty ? neww : 0u;
+            row_st(ops, p0 + (uint32_t)(j * NT + tid), nonempty ? neww : 0u);
         }
     }
     __syncthreads();
