@@ -293,12 +293,18 @@ class QmcIsingGraph:
         state = self.state_ref()[r].astype(bool).copy()
         ops = self.export_ops(r)
         e = self.edges
+        generic = getattr(self, "interactions", None)
         acc = init
         for w in ops:
             acc = fold_fn(acc, state)
             if w:
                 bond, _, out = op_fields(int(w))
-                if bond < len(e):
+                if generic is not None:
+                    vs = generic[bond][1]
+                    state[vs[0]] = bool(out & 1)
+                    if len(vs) == 2:
+                        state[vs[1]] = bool(out & 2)
+                elif bond < len(e):
                     state[e[bond, 0]] = bool(out & 1); state[e[bond, 1]] = bool(out & 2)
                 else:
                     state[(bond - len(e)) % self.nvars] = bool(out & 1)

@@ -407,6 +407,10 @@ def test_generic_interactions_match_oracle(oracle, waves, k, heatbath, loop, clu
     assert g.verify().all()
     if loop:  # two-variable off-diagonal ops (hopping) are really there
         assert any(((int(w) >> 4) - 1) < n and (int(w) & 3) != ((int(w) >> 2) & 3) for r in range(R) for w in g.export_ops(r) if w)
+    # imaginary-time fold (device magnetisation sums vs the generic host-side fold over two-variable off-diagonal ops)
+    s1, s2, sa = g.itime_magnetization()
+    assert g.imaginary_time_fold(lambda a, st: a + (2 * int(st.sum()) - len(st)), 0, r=1) == int(s1[1])
+    assert (int(s1[0]), int(s2[0]), int(sa[0])) == reps[0].itime_magnetization()
     # a model that breaks the Ising symmetry refuses cluster updates like the reference (qmc_runner.rs:224-226)
     broken = im.Qmc.from_interactions(2, [(np.array([1.0, 0, 0, 2.0]), (0,)), (np.full(4, 0.5), (1,))], 4, 1)
     with pytest.raises(im.IsingMcError):
