@@ -283,6 +283,12 @@ __device__ __forceinline__ void row_st(uint32_t *row, uint32_t idx, uint32_t v) 
     *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(row) + (size_t)(idx * 4u)) = v;
 }
 
+__device__ __forceinline__ uint32_t vgpr_copy_u32(uint32_t x) {
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+
 // slot index of (tile, wave, sub-round j, lane)
 template <int W, int K>
 __device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int lane) {
@@ -319,6 +325,9 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         wJv = vgpr_copy(B.wJ); wGv = vgpr_copy(B.gamma); wHv = vgpr_copy(B.wh);
         nJv = vgpr_copy(beta_nb * B.wJ); nGv = vgpr_copy(beta_nb * B.gamma); nHv = vgpr_copy(beta_nb * B.wh);
     }
+    // a few scalars every sub-round needs, pinned into vector registers: the pass is short of scalar registers (they
+    // were being spilled to vector lanes and read back with v_readlane once per use) and has vector registers to spare
+    const uint32_t pE = vgpr_copy_u32(B.E), pN = vgpr_copy_u32(B.N), pNb = vgpr_copy_u32(B.Nb), pM = vgpr_copy_u32(M);
     // Per-wave spin tables T_w[v] (u8, in the o_cur area the cluster scan uses later): bit 0 = spin of v at the
     // wave's current position; bits 1..7 = lane+1 of an off-diagonal op on v inside the sub-round being resolved.
     const uint32_t N = B.N, h_my = (uint32_t)wave * N;
@@ -419,7 +428,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             const bool flipa = (xbits & 1u) != 0u;                        // the op flips its first variable
             const bool flipc = CL ? false : ((xbits & 2u) != 0u);          // ... its second (generic interactions only)
             const bool isev = flipa | flipc;
-            const bool is_empty = (p < M) & !occ;
+            const bool is_empty = (p < pM) & !occ;
             const bool is_diag = occ & !isev;
             uint32_t r0, r1, r2 = 0;
             if (HB) {
@@ -442,18 +451,18 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                     b = lo < B.Nb ? lo : B.Nb - 1;
                 }
             } else {
-                b = occ ? sse_op_bond(wd) : __umulhi(r0, B.Nb);
+                b = occ ? sse_op_bond(wd) : __umulhi(r0, pNb);
             }
             // bond -> variables, kind, preferred alignment, weight w and beta*Nb*w
             uint32_t va, vc, pref;
             bool two, tr;
             double wbond, nbond;
             if constexpr (CL) {
-                two = b < B.E;
+                two = b < pE;
                 const uint32_t e = LDSW(L.o_edges, two ? b : 0u);
-                const uint32_t s1 = b - B.E;  // wraps far above N for two-site bonds
-                tr = s1 < B.N;
-                va = two ? (e & SSE_CE_VAR_MASK) : (tr ? s1 : s1 - B.N);
+                const uint32_t s1 = b - pE;  // wraps far above N for two-site bonds
+                tr = s1 < pN;
+                va = two ? (e & SSE_CE_VAR_MASK) : (tr ? s1 : s1 - pN);
                 vc = two ? ((e >> 15) & SSE_CE_VAR_MASK) : va;
                 pref = two ? ((e >> 30) & 1u) : B.hpos;
                 wbond = two ? wJv : (tr ? wGv : wHv);
@@ -544,7 +553,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 fb[j] = nbond;
             }
             insm[j] = sse_ballot(ins);
-            cb[j] = M + (ins ? 0u : 1u);
+            cb[j] = pM + (ins ? 0u : 1u);
             cw[j] = ins ? sse_op_make(b, sub, sub) : 0u;
             keep[j] = wd;
         }
