@@ -60,6 +60,22 @@ def test_create_rejects_bad_arguments():
     assert lib.isingmc_create(C.byref(cfg), C.byref(h)) == -1  # cutoff0 > capacity
 
 
+def test_create_rejects_bad_generic_interactions():
+    """Argument checks of the generic-interaction path run before any device is touched."""
+    import isingmontecarlo_amd as im
+    with pytest.raises(im.IsingMcError) as ei:  # negative weight (Interaction::new, qmc_runner.rs:511-513)
+        im.Qmc.from_interactions(2, [(np.array([1.0, -0.5, 0, 1.0]), (0,))], 4, 1)
+    assert ei.value.code == -1 and ">= 0" in str(ei.value)
+    with pytest.raises(im.IsingMcError):  # variable outside the model
+        im.Qmc.from_interactions(2, [(np.ones(16), (0, 2))], 4, 1)
+    with pytest.raises(im.IsingMcError):  # the same variable twice
+        im.Qmc.from_interactions(2, [(np.ones(16), (1, 1))], 4, 1)
+    with pytest.raises(im.IsingMcError):  # wrong matrix size for the number of variables
+        im.Qmc.from_interactions(2, [(np.ones(4), (0, 1))], 4, 1)
+    m, off = im.Qmc.interaction_and_offset([3.0, 1.0, 1.0, 2.0])  # Interaction::new_offset: diagonal minimum removed
+    assert off == 2.0 and np.allclose(m, [1.0, 1.0, 1.0, 0.0])
+
+
 def test_null_handle_calls_do_not_crash():
     import isingmontecarlo_amd as im
     lib = im.load_library()
