@@ -129,11 +129,11 @@ def test_many_replicas_stress(oracle):
     # wide batch at the bench geometry: every replica runs the concurrent union-find / flatten / coin phases with
     # its own interleaving, so an ordering bug between workgroup threads shows up as a parity break somewhere
     edges = lat.two_d_ferro(32)
-    R = 256
-    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 1024, 1 << 16, 77, R)
-    g.run(12, 8.0)
-    oracle.batch_timesteps(reps, 12, [8.0] * R)
-    assert_same(g, reps, "32x32 x256")
+    R = 1024  # BASELINE configs[1] at full size: 1024 replicas, 32x32, beta = 16
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 1024, 1 << 17, 77, R)
+    g.run(30, 16.0, flags=1)  # the bench workload (with the directed loop), from the initial cutoff growth on
+    oracle.batch_timesteps(reps, 30, [16.0] * R, 1, 1)
+    assert_same(g, reps, "32x32 x1024")
     assert g.verify().all()
 
 
