@@ -1,0 +1,54 @@
+"""Autocorrelations of sampled observables (qmc::sse::autocorrelations, src/sse/autocorrelations.rs).
+
+Host-side post-processing of the p=0 states a batch samples; numpy FFT (the reference uses rustfft)."""
+import numpy as np
+
+
+def fft_autocorrelation(samples):
+    """fft_autocorrelation (autocorrelations.rs:99-133): `samples` is [T][n] (T samples of n observables).  Every
+    observable is centred and scaled to unit norm, its circular autocorrelation is taken through the FFT, and the
+    result is averaged over the n observables: returns T values, r[0] = 1 (up to rounding)."""
+    x = np.asarray(samples, dtype=np.float64)
+    tmax, n = x.shape
+    x = x - x.mean(axis=0, keepdims=True)
+    norm = np.sqrt((x * x).sum(axis=0, keepdims=True))
+    x = x / norm
+    f = np.fft.fft(x, axis=0)
+    ac = np.fft.ifft(f * np.conj(f), axis=0).real * tmax  # rustfft's inverse is unnormalised
+    return ac.sum(axis=1) / (n * tmax)
+
+
+def variable_autocorrelation(graph, timesteps, beta, sampling_freq=1, r=None):
+    """QmcAutoCorrelations::calculate_variable_autocorrelation (autocorrelations.rs:37-50) for a batch: runs `timesteps`
+    sweeps, samples the p=0 states every `sampling_freq` sweeps and returns the autocorrelation of the +-1 spins, one
+    row per replica (or for replica r only)."""
+    states = []
+    done = 0
+    while done < timesteps:
+        t = min(sampling_freq, timesteps - done)
+        graph.run(t, beta)
+        done += t
+        if done % sampling_freq == 0:
+            states.append(graph.state_ref())
+    st = np.stack(states).astype(np.float64) * 2.0 - 1.0  # [T][R][N]
+    reps = range(st.shape[1]) if r is None else [r]
+    out = np.stack([fft_autocorrelation(st[:, k, :]) for k in reps])
+    return out if r is None else out[0]
+
+
+def spin_product_autocorrelation(graph, timesteps, beta, var_products, sampling_freq=1, r=None):
+    """calculate_spin_product_autocorrelation (autocorrelations.rs:52-75): observables are products of the +-1 spins of
+    each variable group in `var_products`."""
+    states = []
+    done = 0
+    while done < timesteps:
+        t = min(sampling_freq, timesteps - done)
+        graph.run(t, beta)
+        done += t
+        if done % sampling_freq == 0:
+            states.append(graph.state_ref())
+    st = np.stack(states).astype(np.float64) * 2.0 - 1.0
+    prods = np.stack([st[:, :, list(vs)].prod(axis=2) for vs in var_products], axis=2)  # [T][R][len(var_products)]
+    reps = range(st.shape[1]) if r is None else [r]
+    out = np.stack([fft_autocorrelation(prods[:, k, :]) for k in reps])
+    return out if r is None else out[0]

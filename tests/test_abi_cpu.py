@@ -104,3 +104,15 @@ def test_lattice_builders_match_reference_ordering():
     (a, b), j = e[16 + 4]  # i=1, j=0 -> odd column
     assert (a, b) == (1, 5) and j == -1.0
     assert lat.one_d_periodic(16)[-1] == ((15, 0), 1.0)
+
+
+def test_fft_autocorrelation_matches_direct_sum():
+    """fft_autocorrelation (autocorrelations.rs:99-133) against the defining circular sum."""
+    from isingmontecarlo_amd.autocorrelations import fft_autocorrelation
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(37, 5)) + np.linspace(0, 2, 37)[:, None]
+    got = fft_autocorrelation(x)
+    y = x - x.mean(axis=0)
+    y = y / np.sqrt((y * y).sum(axis=0))
+    want = np.array([sum((y[:, i] * np.roll(y[:, i], -t)).sum() for i in range(5)) / 5 for t in range(37)])
+    assert np.allclose(got, want, atol=1e-12) and abs(got[0] - 1.0) < 1e-12
