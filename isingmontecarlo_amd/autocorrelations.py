@@ -7,12 +7,12 @@ import numpy as np
 def fft_autocorrelation(samples):
     """fft_autocorrelation (autocorrelations.rs:99-133): `samples` is [T][n] (T samples of n observables).  Every
     observable is centred and scaled to unit norm, its circular autocorrelation is taken through the FFT, and the
-    result is averaged over the n observables: returns T values, r[0] = 1 (up to rounding)."""
+    result is averaged over the n observables: returns T values, r[0] = 1 (up to rounding) when every observable varied."""
     x = np.asarray(samples, dtype=np.float64)
     tmax, n = x.shape
     x = x - x.mean(axis=0, keepdims=True)
     norm = np.sqrt((x * x).sum(axis=0, keepdims=True))
-    x = x / norm
+    x = np.divide(x, norm, out=np.zeros_like(x), where=norm > 0)  # an observable that never changed contributes 0 (the reference divides by 0 there)
     f = np.fft.fft(x, axis=0)
     ac = np.fft.ifft(f * np.conj(f), axis=0).real * tmax  # rustfft's inverse is unnormalised
     return ac.sum(axis=1) / (n * tmax)
