@@ -224,6 +224,8 @@ def main():
                                     f"{'QmcIsingGraph::timestep = diagonal + RVB sweep + ' if args.rvb else 'Qmc::timestep = diagonal + ' + ('directed loop + ' if not args.no_loop else '')}cluster + free spins"),
                        "replicas_per_gpu": R, "lattice": f"{L}^3" if args.pmj3d else f"{L}x{L}", "beta": beta,
                        "mean_cutoff_M": mean_M, "mean_n": mean_n, "sweeps_per_s": args.steps / dt,
+                       "updates_diagonal_per_s_rank0": slots / dt,  # U_diag: slots visited by the diagonal pass
+                       "updates_offdiagonal_per_s_rank0": float(acc[:, 4].sum()) / dt,  # U_off: cluster + loop vertices
                        "waves_per_replica": g.launch_info()["waves_per_replica"],
                        "slots_per_lane": g.launch_info()["slots_per_lane"],
                        "lds_bytes_per_workgroup": g.launch_info()["lds_bytes"],
