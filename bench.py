@@ -37,6 +37,24 @@ def lattice_edges(l):
     return lat.two_d_ferro(l)
 
 
+def usable_cores():
+    """Host cores this process may really use: the CPU affinity mask, capped by the cgroup CPU quota (the GPU boxes
+    expose every logical CPU of the host but grant a quota of 16 of them to a one-GPU job)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // pr))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(l, beta, flags, seed, budget_s=20.0):
     """Time the CPU oracle (a C restatement of the reference path, kind='port') on this box's host cores."""
     import _oracle
@@ -44,7 +62,7 @@ def cpu_baseline(l, beta, flags, seed, budget_s=20.0):
     _oracle.build()
     edges = lattice_edges(l)
     e, j = lat.split(edges)
-    nthreads = max(1, min(_oracle.lib().ora_max_threads(), os.cpu_count() or 1))
+    nthreads = max(1, min(_oracle.lib().ora_max_threads(), usable_cores()))
     m = _oracle.Model(l * l, e, j, 1.0, 0.0)
     reps = [_oracle.Replica(m, 1 << 18, l * l, seed, 1_000_000 + r) for r in range(nthreads)]
     betas = [beta] * nthreads
@@ -62,7 +80,7 @@ def cpu_baseline(l, beta, flags, seed, budget_s=20.0):
     return {"value": upd / dt, "unit": "spin-op updates/s", "cores": nthreads, "kind": "port",
             "sample": f"{nthreads} replicas (one per thread) x {sweeps} sweeps of the same {l}x{l} beta={beta} "
                       f"workload after 60 equilibration sweeps; C oracle, not the Rust binary",
-            "sweeps_per_s_per_core": sweeps / dt}
+            "sweeps_per_s_per_core": sweeps / dt, "host_logical_cpus": os.cpu_count()}
 
 
 def main():
