@@ -225,7 +225,22 @@ class Replica:
         lib().ora_reset_accumulators(self.ptr)
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU boxes show every logical CPU
+    of the host but grant a one-GPU job a quota of 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def batch_timesteps(replicas, t, betas, freq=1, flags=0, nthreads=0):
+    if nthreads == 0:
+        nthreads = min(usable_cores(), len(replicas))
     arr = (C.c_void_p * len(replicas))(*[r.ptr for r in replicas])
     b = np.ascontiguousarray(np.asarray(betas, dtype=np.float64))
     rc = lib().ora_batch_timesteps(arr, len(replicas), t, _ptr(b, C.c_double), freq, flags, nthreads)
