@@ -418,19 +418,9 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
         uint64_t insm[K]; // insert candidates
         uint32_t trbits = 0; // bit j: the op at stake in sub-round j is a transverse-field op
         uint4 rnd = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
-            const uint32_t wd = word[j];
-            const bool occ = wd != 0u;
-            const uint32_t inb = sse_op_in(wd) & 1u, inc = (sse_op_in(wd) >> 1) & 1u;
-            const uint32_t xbits = sse_op_in(wd) ^ sse_op_out(wd);
-            const bool flipa = (xbits & 1u) != 0u;                        // the op flips its first variable
-            const bool flipc = CL ? false : ((xbits & 2u) != 0u);          // ... its second (generic interactions only)
-            const bool isev = flipa | flipc;
-            const bool is_empty = (p < pM) & !occ;
-            const bool is_diag = occ & !isev;
-            uint32_t r0, r1, r2 = 0;
+        // random numbers and bond of slot j (shared by the two loops below)
+        auto draw_bond = [&](int j, uint32_t p, uint32_t wd, bool occ, bool is_empty, uint32_t &r0, uint32_t &r1) -> uint32_t {
+            uint32_t r2 = 0;
             if (HB) {
                 rnd = rng.draw(SSE_TAG_HEATBATH, p);
                 r0 = rnd.x; r1 = rnd.y; r2 = rnd.z;
@@ -453,6 +443,37 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             } else {
                 b = occ ? sse_op_bond(wd) : __umulhi(r0, pNb);
             }
+            return b;
+        };
+        // General bond table (non-uniform couplings, per-replica couplings, generic interactions): the 16-byte records live
+        // in HBM/L2, so all K of a tile are requested before the first one is used (a load inside the sub-round loop would
+        // expose its full latency K times per tile).
+        uint32_t pre_b[K], pre_r0[K], pre_r1[K];
+        uint4 pre_rec[K];
+        if constexpr (!CL) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
+                const uint32_t wd = word[j];
+                pre_b[j] = draw_bond(j, p, wd, wd != 0u, (p < pM) & (wd == 0u), pre_r0[j], pre_r1[j]);
+                pre_rec[j] = *reinterpret_cast<const uint4 *>(B.bonds + pre_b[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
+            const uint32_t wd = word[j];
+            const bool occ = wd != 0u;
+            const uint32_t inb = sse_op_in(wd) & 1u, inc = (sse_op_in(wd) >> 1) & 1u;
+            const uint32_t xbits = sse_op_in(wd) ^ sse_op_out(wd);
+            const bool flipa = (xbits & 1u) != 0u;                        // the op flips its first variable
+            const bool flipc = CL ? false : ((xbits & 2u) != 0u);          // ... its second (generic interactions only)
+            const bool isev = flipa | flipc;
+            const bool is_empty = (p < pM) & !occ;
+            const bool is_diag = occ & !isev;
+            uint32_t r0, r1, b;
+            if constexpr (CL) b = draw_bond(j, p, wd, occ, is_empty, r0, r1);
+            else { b = pre_b[j]; r0 = pre_r0[j]; r1 = pre_r1[j]; }
             // bond -> variables, kind, preferred alignment, weight w and beta*Nb*w
             uint32_t va, vc, pref;
             bool two, tr;
@@ -468,7 +489,8 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 wbond = two ? wJv : (tr ? wGv : wHv);
                 nbond = two ? nJv : (tr ? nGv : nHv);
             } else {
-                const Bd d = decode_bond<CL, W>(B, L, b);
+                Bd d;
+                { const uint4 q = pre_rec[j]; d.a = q.x & SSE_VAR_MASK; d.c = q.y; d.kp = q.x >> SSE_INFO_SHIFT; d.w = __hiloint2double((int)q.w, (int)q.z); }
                 two = d.c != SSE_NO_VAR;
                 tr = bd_kind(d) == SSE_BOND_TRANSVERSE;
                 va = d.a; vc = two ? d.c : va;
@@ -794,12 +816,19 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
         }
         uint32_t ua[K], uc[K]; // the tile's unions, issued together after the K sub-rounds (unions commute)
         bool utwo[K];
+        uint4 pre_rec[K]; // general bond table: request the tile's K records together (see diagonal_pass)
+        if constexpr (!CL) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) pre_rec[j] = *reinterpret_cast<const uint4 *>(B.bonds + (word[j] ? sse_op_bond(word[j]) : 0u));
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             // straight-line, predicated code: every LDS read uses a safe index and is issued unconditionally
             const uint32_t wd = word[j];
             const bool nonempty = wd != 0u;
-            const Bd d = decode_bond<CL, W>(B, L, nonempty ? sse_op_bond(wd) : 0u);
+            Bd d;
+            if constexpr (CL) d = decode_bond<CL, W>(B, L, nonempty ? sse_op_bond(wd) : 0u);
+            else { const uint4 q = pre_rec[j]; d.a = q.x & SSE_VAR_MASK; d.c = q.y; d.kp = q.x >> SSE_INFO_SHIFT; d.w = 0.0; }
             const uint32_t va = d.a, kind = bd_kind(d);
             const bool two = nonempty & (d.c != SSE_NO_VAR);
             const uint32_t vc = two ? d.c : va;
