@@ -967,6 +967,11 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
 #pragma unroll
             for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, pn0 + (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, pn0 + (uint32_t)(j * NT + tid)); }
         }
+        uint32_t second[K]; // general bond table: the second variable of the tile's K bonds, requested together
+        if constexpr (!CL) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) second[j] = reinterpret_cast<const uint32_t *>(B.bonds + (wd[j] ? sse_op_bond(wd[j]) : 0u))[1];
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const uint32_t w = wd[j];
@@ -975,7 +980,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
             const uint32_t fa = uf.get(nonempty ? (sg[j] & 0xFFFFu) : 0u), fb = uf.get(nonempty ? (sg[j] >> 16) : 0u);
             bool two;
             if constexpr (CL) two = nonempty & (sse_op_bond(w) < B.E);
-            else two = nonempty & (decode_bond<CL, W>(B, L, nonempty ? sse_op_bond(w) : 0u).c != SSE_NO_VAR);
+            else two = nonempty & (second[j] != SSE_NO_VAR);
             // two-site: both legs of variable a carry fa, both legs of variable c carry fb;
             // single-site: the input leg carries fa (incoming segment), the output leg fb (outgoing segment)
             const uint32_t in = sse_op_in(w) ^ (two ? (fa | (fb << 1)) : fa);
