@@ -118,8 +118,8 @@ def main():
     # SSE_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks then share devices and the
     # scalar reductions go through CPU tensors); the driver's runs use nccl = RCCL, one rank per GPU.
     backend = os.environ.get("SSE_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())
+    # one rank per GPU; if the launcher narrowed the visible devices of each rank to one, that one is device 0
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
