@@ -116,3 +116,16 @@ def test_fft_autocorrelation_matches_direct_sum():
     y = y / np.sqrt((y * y).sum(axis=0))
     want = np.array([sum((y[:, i] * np.roll(y[:, i], -t)).sum() for i in range(5)) / 5 for t in range(37)])
     assert np.allclose(got, want, atol=1e-12) and abs(got[0] - 1.0) < 1e-12
+
+
+def test_header_is_plain_c_and_matches_the_python_mirror(tmp_path):
+    """include/isingmc_hip.h is the drop-in boundary: it must compile as C99 on its own and agree with the ctypes mirror."""
+    import os, subprocess
+    import isingmontecarlo_amd as im
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "isingmc_hip.h"\n#include <stdio.h>\nint main(void){ printf("%zu %zu\\n", sizeof(isingmc_config), sizeof(isingmc_interaction)); return 0; }\n')
+    exe = str(tmp_path / "abi")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"), str(src), "-o", exe])
+    a, b = (int(x) for x in subprocess.check_output([exe], text=True).split())
+    assert a == C.sizeof(im._Config) and b == C.sizeof(im._Interaction)
