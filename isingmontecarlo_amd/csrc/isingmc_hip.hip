@@ -307,6 +307,26 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         dev_off.lds_ufcap = po.ufcap; dev_off.lds_words = (uint32_t)(po.lds_bytes / 4);
         b->last_W_off = Wo;
     };
+    bool use_dev_off = false;
+    if (split && (A.domask & SSE_DO_RVB) && !b->W_off && b->W < 16) {
+        // RVB sweeps: the cooperative window scans of an attempt cover 4x more slots per step with 16 waves (the
+        // sequential lane does not care); taken when the cluster tables of that geometry fit as well
+        const LdsPlan p16 = plan_lds(b, 16);
+        if (p16.all_ids_fit) {
+            const DevBatch &D = b->dev;
+            const size_t fixed16 = lds_fixed_words(16, D.N, D.nwords, b->CL ? D.E : 0u);
+            const size_t o_cur16 = fixed16 - ((size_t)16 * D.N + 1) / 2 - ((size_t)16 * D.N + 3) / 4;
+            size_t want = 4 * (o_cur16 + 2 + rvb_fixed_words(D.N, D.E) + (size_t)D.cap);
+            const size_t max_lds = b->lds_total_words * 4;
+            if (want > max_lds) want = max_lds;
+            want &= ~(size_t)7;
+            lc.W = 16;
+            lc.lds_bytes = want > p16.lds_bytes ? want : p16.lds_bytes;
+            dev_off.lds_ufcap = p16.ufcap; dev_off.lds_words = (uint32_t)(lc.lds_bytes / 4);
+            use_dev_off = true;
+            b->last_W_off = 16;
+        }
+    }
     if (loop_only) lc.passes = SSE_PASSES_DIAG; // a lone directed loop uses the small launch geometry too
     else if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB | SSE_DO_LOOP)) || (split && !(A.domask & SSE_DO_RVB))) {
         lc.passes = SSE_PASSES_OFFDIAG;
@@ -318,7 +338,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         for (uint64_t done = 0; done < nsteps; done += per) {
             A.step0 = done;
             A.nsteps = (nsteps - done < per) ? nsteps - done : per;
-            const hipError_t e = launch_dev(lc, lc.passes == SSE_PASSES_OFFDIAG ? dev_off : b->dev, A);
+            const hipError_t e = launch_dev(lc, (use_dev_off || lc.passes == SSE_PASSES_OFFDIAG) ? dev_off : b->dev, A);
             if (e != hipSuccess) return fail_launch(e);
             launches++;
         }
@@ -355,7 +375,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             if (rest || sample) {
                 SweepArgs a2 = A;
                 a2.domask = rest; a2.nsteps = 1; a2.step0 = done;
-                e = launch_dev(lc, lc.passes == SSE_PASSES_OFFDIAG ? dev_off : b->dev, a2);
+                e = launch_dev(lc, (use_dev_off || lc.passes == SSE_PASSES_OFFDIAG) ? dev_off : b->dev, a2);
                 if (e != hipSuccess) return fail_launch(e);
                 launches++; b->pass_launches[1]++;
             }
