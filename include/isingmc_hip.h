@@ -31,6 +31,8 @@ extern "C" {
 #define ISINGMC_ECAPACITY (-3) /* cutoff would exceed the preallocated op-string capacity */
 #define ISINGMC_EINTEGRITY (-4) /* device-side integrity failure (the reference would panic) */
 #define ISINGMC_ENOTIMPL (-5)
+#define ISINGMC_ELIMIT (-6)     /* a directed loop did not close within 64*cutoff+1024 vertices (the reference's loop is unbounded,
+                                   directed_loop.rs:217-301); the replica's flag is cleared by isingmc_clear_errors */
 
 /* update flags (isingmc_timesteps / isingmc_timestep) */
 #define ISINGMC_FLAG_LOOP 1u       /* Qmc::set_do_loop_updates(true): one directed loop per step (qmc_runner.rs:268,366) */
@@ -44,6 +46,10 @@ extern "C" {
 #define ISINGMC_CFG_NO_LDS_TABLES 1u /* keep the bond table in HBM even when it would fit in LDS (testing) */
 #define ISINGMC_CFG_PER_REPLICA_J 4u /* `J` holds nreplicas x nedges couplings (row r = replica r): independent disorder
                                         realisations on one graph.  RVB updates are not available in this mode. */
+#define ISINGMC_CFG_GLOBAL_TABLES 8u /* keep the per-variable scan tables (spins, cut ranks) in a per-replica HBM scratch instead of
+                                        LDS.  Chosen automatically for models whose tables exceed LDS (N >~ 10^4 variables, e.g. a
+                                        32^3 lattice); this flag forces the path on any model (testing).  Needs
+                                        ISINGMC_CFG_NO_LDS_TABLES or non-uniform couplings; slots_per_lane 1 or 4; no RVB updates. */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 
@@ -87,10 +93,20 @@ typedef struct isingmc_config {
  * index = outputs then inputs, first variable most significant, i.e. for k = 2  (out0 out1 in0 in1)  as a 4-bit number.
  * All entries must be >= 0 (they are sampling weights). */
 typedef struct isingmc_interaction {
-    uint32_t nvars;           /* 1 or 2 */
+    uint32_t nvars;           /* 1 or 2 (more: ISINGMC_ENOTIMPL, the operator word holds two variables) */
     uint32_t vars[2];
-    const double *mat;        /* [4^nvars] */
+    uint32_t diagonal_only;   /* 0: mat is the full [4^nvars] matrix (InteractionType::Full); 1: mat holds the [2^nvars] diagonal
+                                 only (InteractionType::Diagonal, qmc_runner.rs:594-610), every off-diagonal weight is 0 */
+    const double *mat;
 } isingmc_interaction;
+
+/* Interaction::at (qmc_runner.rs:573-612): the weight for inputs[nvars] / outputs[nvars] (bytes 0/1).  Host-side, no device
+ * needed; isingmc_create tabulates every interaction through this function. */
+int isingmc_interaction_at(const isingmc_interaction *it, const uint8_t *inputs, const uint8_t *outputs, double *out);
+/* Interaction::sym_under_ising (qmc_runner.rs:639-664), restated with its index range as written there: a full matrix is
+ * compared on indices [0, 2^nvars) against their bit-complements, a diagonal one on [0, 2^(nvars/2)).  (The engine itself
+ * enables cluster updates only when EVERY entry equals its complement's, which implies this.) */
+int isingmc_interaction_sym_under_ising(const isingmc_interaction *it, int *out);
 
 /* QmcIsingGraph::new_with_rng (qmc_ising.rs:131-148) + OpContainerConstructor::new_with_bonds
  * (op_container.rs:110), for R replicas at once. */
@@ -125,6 +141,12 @@ int isingmc_timesteps(isingmc_batch *b, uint64_t t, const double *beta, uint32_t
  * Energy: QmcStepper::get_energy_for_average_n (qmc_ising.rs:805-809) = -(acc0/acc1)/beta + offset. */
 int isingmc_get_accumulators(isingmc_batch *b, uint64_t *out);
 int isingmc_reset_accumulators(isingmc_batch *b);
+/* restore accumulators saved by isingmc_get_accumulators (checkpoint / resume): in[nrows][8] */
+int isingmc_set_accumulators(isingmc_batch *b, const uint64_t *in);
+/* Device-side error flags are sticky per replica (a replica that hit ISINGMC_ECAPACITY / ISINGMC_ELIMIT / an integrity
+ * error is skipped by later launches).  This clears all of them; isingmc_import_ops clears the flag of the replica it
+ * rewrites.  The reference panics instead (release = abort, Cargo.toml:43), so there is nothing to mirror. */
+int isingmc_clear_errors(isingmc_batch *b);
 /* QmcIsingGraph::get_offset (qmc_ising.rs:558) */
 double isingmc_get_offset(const isingmc_batch *b);
 /* the same per replica, out[R] (differs between replicas only with ISINGMC_CFG_PER_REPLICA_J) */
@@ -188,7 +210,8 @@ int isingmc_debug_phase_ticks(isingmc_batch *b, uint64_t *out, int reset);
 int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
 /* build/launch configuration actually in use: out[0]=waves per replica, out[1]=dynamic LDS bytes,
  * out[2]=union-find ids that fit in LDS, out[3]=state words per replica, out[4]=slots per lane,
- * out[5]=1 if the edge table is staged in LDS, out[6]=bit 0: timesteps are issued as two launches (diagonal, rest); bits 8-15: waves per replica of the
+ * out[5]=1 if the edge table is staged in LDS, out[6]=bit 0: timesteps are issued as two launches (diagonal, rest); bit 1: per-variable
+ * tables live in HBM (ISINGMC_CFG_GLOBAL_TABLES path); bits 8-15: waves per replica of the
  * most recent off-diagonal launch,
  * out[7]=dynamic LDS bytes of the diagonal-pass launch */
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]);

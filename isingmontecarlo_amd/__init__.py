@@ -13,16 +13,18 @@ import numpy as np
 from . import _build
 
 __all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
-           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J"]
+           "interaction_at", "interaction_sym_under_ising",
+           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J", "CFG_GLOBAL_TABLES"]
 
 FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
 FLAG_PREP = 0x10000
 CFG_NO_LDS_TABLES = 1
 CFG_PER_REPLICA_J = 4  # J is [nreplicas][nedges]: one disorder realisation per replica
+CFG_GLOBAL_TABLES = 8  # per-variable scan tables in HBM instead of LDS (automatic for large models; forced by this flag)
 CFG_FUSED_LAUNCH = 2  # whole timesteps in one kernel launch (default: diagonal launch + off-diagonal launch)
 ALL = 0xFFFFFFFF
 
-_ERRNAMES = {-1: "EINVAL", -2: "ENODEVICE", -3: "ECAPACITY", -4: "EINTEGRITY", -5: "ENOTIMPL"}
+_ERRNAMES = {-1: "EINVAL", -2: "ENODEVICE", -3: "ECAPACITY", -4: "EINTEGRITY", -5: "ENOTIMPL", -6: "ELIMIT"}
 
 
 class IsingMcError(RuntimeError):
@@ -33,7 +35,7 @@ class IsingMcError(RuntimeError):
 
 class _Interaction(C.Structure):
     """include/isingmc_hip.h: isingmc_interaction"""
-    _fields_ = [("nvars", C.c_uint32), ("vars", C.c_uint32 * 2), ("mat", C.POINTER(C.c_double))]
+    _fields_ = [("nvars", C.c_uint32), ("vars", C.c_uint32 * 2), ("diagonal_only", C.c_uint32), ("mat", C.POINTER(C.c_double))]
 
 
 class _Config(C.Structure):
@@ -62,6 +64,10 @@ SYMBOLS = {
     "isingmc_timesteps": (C.c_int, [_vp, _u64, _P(_f64), _u32, _u32]),
     "isingmc_get_accumulators": (C.c_int, [_vp, _P(_u64)]),
     "isingmc_reset_accumulators": (C.c_int, [_vp]),
+    "isingmc_set_accumulators": (C.c_int, [_vp, _P(_u64)]),
+    "isingmc_clear_errors": (C.c_int, [_vp]),
+    "isingmc_interaction_at": (C.c_int, [_P(_Interaction), _P(C.c_uint8), _P(C.c_uint8), _P(_f64)]),
+    "isingmc_interaction_sym_under_ising": (C.c_int, [_P(_Interaction), _P(C.c_int)]),
     "isingmc_get_offset": (_f64, [_vp]),
     "isingmc_num_bonds": (_u32, [_vp]),
     "isingmc_get_state": (C.c_int, [_vp, _u32, _P(C.c_uint8)]),
@@ -127,6 +133,43 @@ def _ptr(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+def _full_matrix(mat, k):
+    """A [2^k] diagonal (InteractionType::Diagonal) expanded to the full [4^k] layout (index = outputs then inputs)."""
+    m = np.asarray(mat, dtype=np.float64)
+    if len(m) == 4 ** k:
+        return m.copy()
+    full = np.zeros(4 ** k)
+    for s_ in range(2 ** k):
+        full[(s_ << k) | s_] = m[s_]
+    return full
+
+
+def interaction_at(mat, inputs, outputs):
+    """Interaction::at (qmc_runner.rs:573-612) through the C ABI (host-side helper, no device needed)."""
+    lib = load_library()
+    m = np.ascontiguousarray(np.asarray(mat, dtype=np.float64))
+    k = len(inputs)
+    it = _Interaction(nvars=k, diagonal_only=1 if len(m) == 2 ** k else 0, mat=_ptr(m, C.c_double))
+    i = np.ascontiguousarray(np.asarray(inputs, dtype=np.uint8)); o = np.ascontiguousarray(np.asarray(outputs, dtype=np.uint8))
+    out = C.c_double(0.0)
+    rc = lib.isingmc_interaction_at(C.byref(it), _ptr(i, C.c_uint8), _ptr(o, C.c_uint8), C.byref(out))
+    if rc:
+        raise IsingMcError(rc, "bad interaction")
+    return out.value
+
+
+def interaction_sym_under_ising(mat, k):
+    """Interaction::sym_under_ising (qmc_runner.rs:639-664) through the C ABI."""
+    lib = load_library()
+    m = np.ascontiguousarray(np.asarray(mat, dtype=np.float64))
+    it = _Interaction(nvars=k, diagonal_only=1 if len(m) == 2 ** k else 0, mat=_ptr(m, C.c_double))
+    out = C.c_int(0)
+    rc = lib.isingmc_interaction_sym_under_ising(C.byref(it), C.byref(out))
+    if rc:
+        raise IsingMcError(rc, "bad interaction")
+    return bool(out.value)
+
+
 class QmcIsingGraph:
     """Batch of R transverse-field Ising SSE graphs on one GPU.
 
@@ -136,17 +179,19 @@ class QmcIsingGraph:
 
     def __init__(self, edges, transverse, longitudinal, cutoff, seed, state=None, nreplicas=1,
                  capacity=None, replica_offset=0, device=-1, waves_per_replica=0, slots_per_lane=0,
-                 cfg_flags=0, lds_uf_ids_limit=0, waves_offdiag=0, couplings=None):
+                 cfg_flags=0, lds_uf_ids_limit=0, waves_offdiag=0, couplings=None, nvars=None):
         """`couplings` (float64 [nreplicas][nedges]) gives every replica its own J values on the same graph (disorder
-        realisations, BASELINE configs[4]); the J of `edges` is then ignored."""
+        realisations, BASELINE configs[4]); the J of `edges` is then ignored.  `nvars` overrides the reference's
+        "largest edge index + 1" (qmc_ising.rs:92) and allows graphs without any edge (the reference's RVB fixtures,
+        tests/check_rvb_crash.rs:68-110, run on isolated variables)."""
         lib = load_library()
         self._lib = lib
         self._h = None
-        ed = np.ascontiguousarray(np.array([[a, b] for (a, b), _ in edges], dtype=np.uint32))
+        ed = np.ascontiguousarray(np.array([[a, b] for (a, b), _ in edges], dtype=np.uint32).reshape(-1, 2))
         js = np.ascontiguousarray(np.array([j for _, j in edges], dtype=np.float64))
-        if len(ed) == 0:
-            raise IsingMcError(-1, "at least one edge is required")
-        self.nvars = int(ed.max()) + 1  # qmc_ising.rs:92
+        if len(ed) == 0 and nvars is None:
+            raise IsingMcError(-1, "at least one edge (or an explicit nvars) is required")
+        self.nvars = int(nvars) if nvars is not None else int(ed.max()) + 1  # qmc_ising.rs:92
         self.nreplicas = int(nreplicas)
         self.transverse, self.longitudinal = float(transverse), float(longitudinal)
         if couplings is not None:
@@ -380,10 +425,13 @@ class QmcIsingGraph:
         words = np.zeros(int(offs[-1]), dtype=np.uint32)
         for r in range(self.nreplicas):
             words[offs[r]:offs[r + 1]] = self.export_ops(r, int(cut[r]))
-        np.savez_compressed(path, format=np.array([1], dtype=np.uint32), nvars=np.array([self.nvars], dtype=np.uint32),
+        generic = getattr(self, "interactions", None)
+        gm = np.stack([m if len(m) == 16 else np.concatenate([m, np.zeros(12)]) for m, _ in generic]) if generic else np.zeros((0, 16))
+        gv = np.array([[len(v), v[0], v[1] if len(v) == 2 else 0] for _, v in generic], dtype=np.uint32) if generic else np.zeros((0, 3), dtype=np.uint32)
+        np.savez_compressed(path, format=np.array([2], dtype=np.uint32), nvars=np.array([self.nvars], dtype=np.uint32),
                             edges=self.edges, J=self.J, transverse=self.transverse, longitudinal=self.longitudinal,
                             cutoff=cut, offsets=offs, words=words, state=self.state_ref(), epoch=self.get_epoch(),
-                            accumulators=self.accumulators())
+                            accumulators=self.accumulators(), interaction_mats=gm, interaction_vars=gv)
 
     def load_checkpoint(self, path):
         """Restore what save_checkpoint wrote into this batch (same graph and number of replicas required)."""
@@ -392,13 +440,35 @@ class QmcIsingGraph:
             raise IsingMcError(-1, "checkpoint belongs to a different model or batch size")
         if not np.array_equal(z["J"], self.J) or float(z["transverse"]) != self.transverse or float(z["longitudinal"]) != self.longitudinal:
             raise IsingMcError(-1, "checkpoint belongs to a different Hamiltonian")
+        generic = getattr(self, "interactions", None)
+        if "interaction_vars" in z.files:  # generic Hamiltonians: the matrices and variables must agree too
+            gv, gm = z["interaction_vars"], z["interaction_mats"]
+            mine_v = np.array([[len(v), v[0], v[1] if len(v) == 2 else 0] for _, v in generic], dtype=np.uint32) if generic else np.zeros((0, 3), dtype=np.uint32)
+            mine_m = np.stack([m if len(m) == 16 else np.concatenate([m, np.zeros(12)]) for m, _ in generic]) if generic else np.zeros((0, 16))
+            if gv.shape != mine_v.shape or not np.array_equal(gv, mine_v) or not np.array_equal(gm, mine_m):
+                raise IsingMcError(-1, "checkpoint belongs to a different set of interactions")
+        elif generic:
+            raise IsingMcError(-1, "checkpoint does not record its interactions (format 1): cannot be matched to a generic model")
+        # the cutoff is part of the Philox trajectory (slots beyond it are never visited): a batch that already carries a
+        # larger cutoff than the checkpoint cannot resume bit-exactly (cutoffs only grow, fast_ops.rs:1258-1262)
+        if (self.get_cutoff() > z["cutoff"]).any():
+            raise IsingMcError(-1, "this batch already has a larger cutoff than the checkpoint: build it with cutoff <= the saved one")
         offs, words = z["offsets"], z["words"]
         self.set_state(z["state"])
         for r in range(self.nreplicas):
-            self.import_ops(words[offs[r]:offs[r + 1]], r)
+            self.import_ops(words[offs[r]:offs[r + 1]], r)  # also clears the replica's device error flag
         self.set_cutoffs(z["cutoff"])
         ep = np.ascontiguousarray(z["epoch"].astype(np.uint64))
         self._check(self._lib.isingmc_set_epoch(self._h, _ptr(ep, C.c_uint64)))
+        acc = np.ascontiguousarray(z["accumulators"].astype(np.uint64))
+        if acc.shape == (self._acc_rows, 8):
+            self._check(self._lib.isingmc_set_accumulators(self._h, _ptr(acc, C.c_uint64)))
+        else:
+            raise IsingMcError(-1, "checkpoint accumulators have a different row layout (set_accumulator_rows first)")
+
+    def clear_errors(self):
+        """Clear the sticky per-replica device error flags (ECAPACITY / ELIMIT / EINTEGRITY)."""
+        self._check(self._lib.isingmc_clear_errors(self._h))
 
     def verify(self):
         out = np.zeros(self.nreplicas, dtype=np.uint8)
@@ -426,7 +496,8 @@ class QmcIsingGraph:
         out = (C.c_uint32 * 8)()
         self._check(self._lib.isingmc_get_launch_info(self._h, out))
         return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3],
-                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), waves_offdiag=(out[6] >> 8) & 0xFF,
+                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), global_tables=bool(out[6] & 2),
+                    waves_offdiag=(out[6] >> 8) & 0xFF,
                     lds_bytes_diagonal=out[7])
 
     def debug_phase_ticks(self, reset=True):
@@ -440,7 +511,7 @@ class QmcIsingGraph:
     def into_qmc(self, do_loop_updates=False):
         """IntoQmc::into_qmc (qmc_ising.rs:943-976): same container driven through Qmc::timestep."""
         q = Qmc.__new__(Qmc)
-        q.__dict__ = self.__dict__
+        q.__dict__ = dict(self.__dict__)  # its own dict: the handle moves to q, this object is left empty
         q._flags = (self._flags & FLAG_HEATBATH) | (FLAG_LOOP if do_loop_updates else 0)
         self._h = None
         return q
@@ -499,14 +570,17 @@ class Qmc(QmcIsingGraph):
         for i, (mat, vs) in enumerate(interactions):
             m = np.ascontiguousarray(np.asarray(mat, dtype=np.float64))
             vs = [int(v) for v in vs]
-            if len(m) != 4 ** len(vs) or len(vs) not in (1, 2):
-                raise IsingMcError(-1, "interaction matrices must have 4^k entries for k = 1 or 2 variables")
+            if len(vs) > 2:
+                raise IsingMcError(-5, "interactions on more than two variables are not implemented")
+            if len(vs) not in (1, 2) or len(m) not in (4 ** len(vs), 2 ** len(vs)):
+                raise IsingMcError(-1, "interaction matrices must have 4^k (full) or 2^k (diagonal) entries for k = 1 or 2 variables")
             keep.append(m)
             arr[i].nvars = len(vs)
             arr[i].vars[0] = vs[0]
             arr[i].vars[1] = vs[1] if len(vs) == 2 else 0
+            arr[i].diagonal_only = 1 if len(m) == 2 ** len(vs) else 0
             arr[i].mat = m.ctypes.data_as(C.POINTER(C.c_double))
-        self.interactions = [(np.array(m), list(v)) for (m, v) in interactions]
+        self.interactions = [(_full_matrix(m, len(v)), list(v)) for (m, v) in interactions]
         # host-side mirrors used by imaginary_time_fold: bond -> variables
         self.edges = np.zeros((0, 2), dtype=np.uint32)
         self.J = np.zeros(0)
@@ -534,8 +608,9 @@ class Qmc(QmcIsingGraph):
             def sym(m, k):
                 m = np.asarray(m); size = 4 ** k
                 return all(abs(m[i] - m[(size - 1) ^ i]) < np.finfo(float).eps for i in range(size))
-            has_edges = any(len(v) == 1 and np.ptp(np.asarray(m)) < np.finfo(float).eps for m, v in interactions)
-            do_cluster_updates = has_edges and all(sym(m, len(v)) for m, v in interactions)
+            full = self.interactions
+            has_edges = any(len(v) == 1 and np.ptp(np.asarray(m)) < np.finfo(float).eps for m, v in full)
+            do_cluster_updates = has_edges and all(sym(m, len(v)) for m, v in full)
         self._flags = (0 if do_cluster_updates else FLAG_NO_CLUSTER) | (FLAG_LOOP if do_loop_updates else 0)
         self._acc_rows = self.nreplicas
         return self

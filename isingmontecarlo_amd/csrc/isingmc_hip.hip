@@ -16,7 +16,7 @@ static thread_local std::string g_create_error;
 
 struct isingmc_batch {
     DevBatch dev{};
-    uint32_t W = 8, K = 4, CL = 0;
+    uint32_t W = 8, K = 4, mode = SSE_MODE_GENERAL; // mode: SSE_MODE_* (bond decode / where the per-variable tables live)
     uint32_t W_off = 0;                 // waves per replica of the off-diagonal launches; 0 = decide per launch (16 when its tables fit in LDS)
     uint32_t last_W_off = 0;
     uint64_t steps_per_launch = 0;
@@ -176,10 +176,17 @@ __global__ __launch_bounds__(256) void itime_magnetization_kernel(DevBatch B, lo
     }
 }
 
-static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges) {
+static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, bool tg = false) {
     // mirrors Lds<W>::carve up to and including o_cl: state, touched bits, touched bytes, round buffers, misc, chunk counters,
-    // edge table, per-wave rank tables (u16) and marker tables (u8)
+    // edge table, per-wave rank tables (u16) and marker tables (u8); with the tables in HBM (tg) only the bit arrays remain
+    if (tg) return (size_t)nwords * 2 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges;
     return (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
+}
+static bool is_tg(const isingmc_batch *b) { return b->mode == SSE_MODE_GLOBAL_TABLES; }
+// dynamic LDS of the diagonal-pass launch: the fixed regions up to the per-wave tables, which it uses as [W][N] spin bytes
+static size_t diag_lds_bytes(const isingmc_batch *b) {
+    const size_t words = is_tg(b) ? b->lds_fixed_words_ : b->lds_fixed_words_ - ((size_t)b->W * b->dev.N + 1) / 2;
+    return (4 * words + 7) & ~(size_t)7;
 }
 
 // LDS footprint of the next launch.  The union-find of the cluster pass lives in LDS as 16-bit parents when all
@@ -189,11 +196,12 @@ static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t 
 struct LdsPlan { uint32_t W, ufcap; size_t lds_bytes; bool all_ids_fit; };
 static LdsPlan plan_lds(const isingmc_batch *b, uint32_t W) {
     const DevBatch &D = b->dev;
-    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, b->CL ? D.E : 0u);
+    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u, is_tg(b));
     const size_t ids_max = (size_t)W * D.N + D.cap;
     const size_t want = (size_t)W * D.N + b->max_ntrans + b->max_ntrans / 16 + 384;
     size_t ids = want;
     if (b->uf_ids_limit) ids = b->uf_ids_limit;
+    if (is_tg(b)) ids = 0; // tables in HBM: the union-find lives there too
     if (ids > 65535) ids = 65535;
     if (ids > ids_max) ids = ids_max;
     auto words = [&](size_t n) { return (n + 1) / 2 + (D.has_long ? 2 * ((n + 31) / 32) : 0); };
@@ -201,7 +209,7 @@ static LdsPlan plan_lds(const isingmc_batch *b, uint32_t W) {
     LdsPlan p;
     p.W = W; p.ufcap = (uint32_t)ids;
     p.lds_bytes = (4 * (fixed + words(ids)) + 7) & ~(size_t)7;
-    p.all_ids_fit = fixed + 64 <= b->lds_total_words && ids >= (want < ids_max ? want : ids_max) && !b->uf_ids_limit;
+    p.all_ids_fit = !is_tg(b) && fixed + 64 <= b->lds_total_words && ids >= (want < ids_max ? want : ids_max) && !b->uf_ids_limit;
     return p;
 }
 static void size_lds(isingmc_batch *b) {
@@ -234,6 +242,12 @@ static int check_errors(isingmc_batch *b) {
                 b->err = buf;
                 return ISINGMC_ECAPACITY;
             }
+            if (err[r] == 3u) {
+                snprintf(buf, sizeof buf, "replica %u: directed loop still open after 64*cutoff+1024 vertices (the reference has no bound; "
+                                          "clear with isingmc_clear_errors and continue)", r);
+                b->err = buf;
+                return ISINGMC_ELIMIT;
+            }
             snprintf(buf, sizeof buf, "replica %u: device integrity error %u", r, err[r]);
             b->err = buf;
             return ISINGMC_EINTEGRITY;
@@ -258,6 +272,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     }
     if ((domask & SSE_DO_RVB) && b->generic) { b->err = "RVB updates are Ising-specific: not available with generic interactions"; return ISINGMC_ENOTIMPL; }
     if ((domask & SSE_DO_CLUSTER) && b->generic && !b->generic_sym) { b->err = "Cannot perform cluster updates on graphs that break ising symmetry."; return ISINGMC_ENOTIMPL; } // qmc_runner.rs:224-226
+    if ((domask & SSE_DO_RVB) && is_tg(b)) { b->err = "RVB updates keep their working set in LDS: not available for models whose per-variable tables live in HBM"; return ISINGMC_ENOTIMPL; }
     if ((domask & SSE_DO_RVB) && b->per_replica_J) { b->err = "RVB updates with per-replica couplings are not implemented"; return ISINGMC_ENOTIMPL; }
     A.sampling_freq = freq;
     A.domask = domask & 0xFFFFu;
@@ -265,7 +280,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     A.out_u32 = out_host ? b->d_out : nullptr;
     A.rvb_updates = b->rvb_updates;
     LaunchCfg lc{};
-    lc.W = b->W; lc.K = b->K; lc.CL = b->CL; lc.phase = (domask >> 16) & 1u; lc.stream = b->stream;
+    lc.W = b->W; lc.K = b->K; lc.mode = b->mode; lc.phase = (domask >> 16) & 1u; lc.stream = b->stream;
     size_lds(b);
     lc.lds_bytes = ((domask & SSE_DO_RVB) && b->lds_bytes_rvb > b->lds_bytes) ? b->lds_bytes_rvb : b->lds_bytes;
     b->dev.lds_words = (uint32_t)(lc.lds_bytes / 4);
@@ -314,7 +329,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         const LdsPlan p16 = plan_lds(b, 16);
         if (p16.all_ids_fit) {
             const DevBatch &D = b->dev;
-            const size_t fixed16 = lds_fixed_words(16, D.N, D.nwords, b->CL ? D.E : 0u);
+            const size_t fixed16 = lds_fixed_words(16, D.N, D.nwords, b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u);
             const size_t o_cur16 = fixed16 - ((size_t)16 * D.N + 1) / 2 - ((size_t)16 * D.N + 3) / 4;
             size_t want = 4 * (o_cur16 + 2 + rvb_fixed_words(D.N, D.E) + (size_t)D.cap);
             const size_t max_lds = b->lds_total_words * 4;
@@ -351,7 +366,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         ld.W = b->W;
         ld.passes = SSE_PASSES_DIAG;
         // the diagonal launch needs the fixed regions up to the per-wave tables, which it uses as [W][N] bytes
-        ld.lds_bytes = (4 * (b->lds_fixed_words_ - ((size_t)b->W * b->dev.N + 1) / 2) + 7) & ~(size_t)7;
+        ld.lds_bytes = diag_lds_bytes(b);
         const uint32_t rest = A.domask & ~diag_bits;
         constexpr size_t MAX_TIMED = 256;
         const size_t want_ev = 3 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
@@ -403,6 +418,27 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
 
 extern "C" {
 
+int isingmc_interaction_at(const isingmc_interaction *it, const uint8_t *inputs, const uint8_t *outputs, double *out) {
+    if (!it || !it->mat || !inputs || !outputs || !out || it->nvars == 0 || it->nvars > 2) return ISINGMC_EINVAL;
+    // index_from_state (qmc_runner.rs:666-679): outputs then inputs, first variable most significant
+    uint32_t iin = 0, iout = 0;
+    for (uint32_t k = 0; k < it->nvars; ++k) { iin = (iin << 1) | (inputs[k] ? 1u : 0u); iout = (iout << 1) | (outputs[k] ? 1u : 0u); }
+    if (it->diagonal_only) *out = (iin == iout) ? it->mat[iin] : 0.0;
+    else *out = it->mat[(iout << it->nvars) | iin];
+    return ISINGMC_OK;
+}
+int isingmc_interaction_sym_under_ising(const isingmc_interaction *it, int *out) {
+    if (!it || !it->mat || !out || it->nvars == 0 || it->nvars > 2) return ISINGMC_EINVAL;
+    const uint32_t n = it->nvars;
+    const uint32_t mask = it->diagonal_only ? ((1u << n) - 1u) : ((1u << (2 * n)) - 1u);
+    const uint32_t upto = it->diagonal_only ? (1u << (n >> 1)) : (1u << n);
+    int sym = 1;
+    for (uint32_t i = 0; i < upto; ++i)
+        if (!(std::fabs(it->mat[i] - it->mat[(~i) & mask]) < DBL_EPSILON)) sym = 0;
+    *out = sym;
+    return ISINGMC_OK;
+}
+
 int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (!cfg || !out || cfg->struct_size != sizeof(isingmc_config)) { g_create_error = "bad config pointer or struct_size"; return ISINGMC_EINVAL; }
     *out = nullptr;
@@ -412,14 +448,18 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         if (cfg->flags & ISINGMC_CFG_PER_REPLICA_J) { g_create_error = "per-replica couplings are not available with generic interactions"; return ISINGMC_EINVAL; }
         for (uint32_t i = 0; i < cfg->ninteractions; ++i) {
             const isingmc_interaction &it = cfg->interactions[i];
+            if (it.nvars > 2) { // qmc_runner.rs:415-680 allows any k; the 32-bit operator word holds two variables
+                g_create_error = "interactions on more than two variables are not implemented (operator word = 2 in + 2 out bits)"; return ISINGMC_ENOTIMPL;
+            }
             if ((it.nvars != 1 && it.nvars != 2) || !it.mat || it.vars[0] >= cfg->nvars || (it.nvars == 2 && (it.vars[1] >= cfg->nvars || it.vars[1] == it.vars[0]))) {
                 g_create_error = "interaction must act on 1 or 2 distinct variables inside the model and carry a matrix"; return ISINGMC_EINVAL;
             }
-            for (uint32_t k = 0; k < (it.nvars == 2 ? 16u : 4u); ++k)
+            for (uint32_t k = 0; k < (it.diagonal_only ? (1u << it.nvars) : (1u << (2 * it.nvars))); ++k)
                 if (!(it.mat[k] >= 0.0) || !std::isfinite(it.mat[k])) { g_create_error = "interaction matrix entries must be finite and >= 0"; return ISINGMC_EINVAL; }
         }
     } else
-    if (cfg->nreplicas == 0 || cfg->nvars == 0 || cfg->nedges == 0 || !cfg->edges || !cfg->J) { g_create_error = "nreplicas, nvars, nedges must be > 0 and edges/J non-null"; return ISINGMC_EINVAL; }
+    if (cfg->nreplicas == 0 || cfg->nvars == 0 || (cfg->nedges != 0 && (!cfg->edges || !cfg->J))) { g_create_error = "nreplicas and nvars must be > 0 and edges/J non-null when nedges > 0"; return ISINGMC_EINVAL; }
+    if (cfg->capacity == 0) { g_create_error = "capacity must be > 0"; return ISINGMC_EINVAL; }
     if (cfg->cutoff0 > cfg->capacity) { g_create_error = "cutoff0 exceeds capacity"; return ISINGMC_EINVAL; }
     if (cfg->nvars > SSE_VAR_MASK) { g_create_error = "too many variables"; return ISINGMC_EINVAL; }
     if (!generic && !(cfg->transverse >= 0.0)) { g_create_error = "transverse field must be >= 0"; return ISINGMC_EINVAL; }
@@ -466,16 +506,11 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         for (uint32_t i = 0; i < D.Nb; ++i) {
             const isingmc_interaction &it = cfg->interactions[i];
             double *mb = b->mats_host.data() + (size_t)i * 16;
-            if (it.nvars == 2) {
-                for (uint32_t in = 0; in < 4; ++in)
-                    for (uint32_t out = 0; out < 4; ++out) {
-                        const uint32_t ref = ((out & 1u) << 3) | (((out >> 1) & 1u) << 2) | ((in & 1u) << 1) | ((in >> 1) & 1u);
-                        mb[in | (out << 2)] = it.mat[ref];
-                    }
-            } else {
-                for (uint32_t in = 0; in < 2; ++in)
-                    for (uint32_t out = 0; out < 2; ++out) mb[in | (out << 2)] = it.mat[(out << 1) | in];
-            }
+            for (uint32_t in = 0; in < (1u << it.nvars); ++in)      // device layout: bit 0 = first variable
+                for (uint32_t out = 0; out < (1u << it.nvars); ++out) {
+                    const uint8_t ib[2] = {(uint8_t)(in & 1u), (uint8_t)((in >> 1) & 1u)}, ob[2] = {(uint8_t)(out & 1u), (uint8_t)((out >> 1) & 1u)};
+                    (void)isingmc_interaction_at(&it, ib, ob, &mb[in | (out << 2)]);
+                }
             double maxw = 0.0; // heatbath.rs:130-146 make_bond_weights: largest diagonal element
             for (uint32_t st = 0; st < (it.nvars == 2 ? 4u : 2u); ++st) maxw = std::max(maxw, mb[st | (st << 2)]);
             const uint32_t kind = it.nvars == 2 ? SSE_BOND_TWO_SITE
@@ -546,21 +581,32 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     b->fused_launch = (cfg->flags & ISINGMC_CFG_FUSED_LAUNCH) != 0;
     const bool CL = !generic && !perJ && D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
     const uint32_t ledges = CL ? D.E : 0u;
-    while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : (W == 6 ? 4 : W >> 1);
-    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges);
-    if (fixed + 64 > total_words) { b->err = "model too large: per-variable scan tables do not fit in LDS"; return fail(ISINGMC_ENOTIMPL); }
+    // Per-variable scan tables: in LDS while W copies of them fit (with room for a union-find), otherwise in a per-replica
+    // HBM scratch served by L2 / Infinity Cache (MODE 2; ISINGMC_CFG_GLOBAL_TABLES forces it on any model).
+    bool TG = (cfg->flags & ISINGMC_CFG_GLOBAL_TABLES) != 0;
+    if (!TG && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) {
+        if (cfg->waves_per_replica) { // explicit geometry: keep the LDS tables if a smaller W makes them fit (previous behaviour)
+            while (W > 1 && lds_fixed_words(W, D.N, D.nwords, ledges) + 4096 > total_words) W = (W == 4) ? 1 : (W == 6 ? 4 : W >> 1);
+            if (lds_fixed_words(W, D.N, D.nwords, ledges) + 64 > total_words) TG = true, W = cfg->waves_per_replica;
+        } else TG = true;
+    }
+    if (TG && CL) { b->err = "ISINGMC_CFG_GLOBAL_TABLES needs the general bond table: combine it with ISINGMC_CFG_NO_LDS_TABLES"; return fail(ISINGMC_EINVAL); }
+    if (TG && K == 2) K = 4;
+    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges, TG);
+    if (fixed + 64 > total_words) { b->err = "model too large: the spin-state bit arrays alone exceed LDS"; return fail(ISINGMC_ENOTIMPL); }
     // off-diagonal launches may use their own wave count (see run()): explicit, or decided per launch (then up to 16)
     uint32_t W_off = cfg->waves_offdiag;
     if (W_off != 0 && W_off != 1 && W_off != 4 && W_off != 6 && W_off != 8 && W_off != 16) { b->err = "waves_offdiag must be 0, 1, 4, 6, 8 or 16"; return fail(ISINGMC_EINVAL); }
     if (!W_off && cfg->waves_per_replica) W_off = W; // an explicit waves_per_replica pins both kinds of launch
-    if (W_off && lds_fixed_words(W_off, D.N, D.nwords, ledges) + 64 > total_words) W_off = W;
-    const bool w16_possible = lds_fixed_words(16, D.N, D.nwords, ledges) + 64 <= total_words;
+    if (TG) W_off = W;                               // tables in HBM: one geometry for every launch
+    if (W_off && lds_fixed_words(W_off, D.N, D.nwords, ledges, TG) + 64 > total_words) W_off = W;
+    const bool w16_possible = !TG && lds_fixed_words(16, D.N, D.nwords, ledges) + 64 <= total_words;
     const uint32_t Wmax = W_off ? (W_off > W ? W_off : W) : ((W < 16 && w16_possible) ? 16u : W);
     const size_t ids_max = (size_t)Wmax * D.N + D.cap;
     // chunk grid for the per-chunk counters: <= SSE_MAX_CHUNKS chunks of CH slots, CH a multiple of 256
     D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
     D.nchunks = (D.cap + D.CH - 1) / D.CH;
-    b->W = W; b->K = K; b->CL = CL ? 1u : 0u; b->W_off = W_off;
+    b->W = W; b->K = K; b->mode = TG ? SSE_MODE_GLOBAL_TABLES : (CL ? SSE_MODE_LDS_EDGES : SSE_MODE_GENERAL); b->W_off = W_off;
     { // row stride: whole tiles, plus room for the (unused) prefetch of a cluster-scan wave whose chunk range is empty
         const size_t tile = (Wmax % W == 0 ? (size_t)Wmax : (size_t)Wmax * W) * 64 * K; // whole tiles of either launch geometry
         const size_t need1 = ((size_t)D.cap + tile - 1) / tile * tile;
@@ -571,7 +617,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     b->lds_fixed_words_ = fixed; b->lds_total_words = total_words; b->uf_ids_limit = cfg->lds_uf_ids_limit;
     { // the RVB pass reuses everything from the scan tables on: launches that run it get enough LDS for its scratch
       // and constant-op table (other launches keep the smaller footprint, which decides workgroups per CU)
-        const size_t o_cur = fixed - ((size_t)W * D.N + 1) / 2 - ((size_t)W * D.N + 3) / 4;
+        const size_t o_cur = TG ? fixed : fixed - ((size_t)W * D.N + 1) / 2 - ((size_t)W * D.N + 3) / 4;
         const size_t want = 4 * (o_cur + 2 + rvb_fixed_words(D.N, D.E) + (size_t)D.cap);
         b->lds_bytes_rvb = (want < (size_t)max_lds ? want : (size_t)max_lds) & ~(size_t)7;
     }
@@ -643,6 +689,10 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     }
     const size_t ufstride = ids_max + 2 * ((ids_max + 31) / 32);
     if ((rc = dalloc(b, &D.uf_scratch, (size_t)D.R * ufstride, false))) return fail(rc);
+    if (TG) {
+        D.tbl_stride = (uint32_t)((((size_t)Wmax * D.N * 3 + D.N) + 15) & ~(size_t)15);
+        if ((rc = dalloc(b, &D.tbl, (size_t)D.R * D.tbl_stride))) return fail(rc);
+    }
     if ((rc = dalloc(b, &b->d_beta, D.R))) return fail(rc);
     if ((rc = dalloc(b, &b->d_out, D.R))) return fail(rc);
     if ((rc = dalloc(b, &b->d_vstate, (size_t)D.R * D.nwords))) return fail(rc);
@@ -727,6 +777,21 @@ int isingmc_get_accumulators(isingmc_batch *b, uint64_t *out) {
     if (!b || !out) return ISINGMC_EINVAL;
     HIP_TRY(b, hipSetDevice(b->device));
     HIP_TRY(b, hipMemcpy(out, b->dev.acc, sizeof(uint64_t) * 8 * b->acc_rows, hipMemcpyDeviceToHost));
+    return ISINGMC_OK;
+}
+int isingmc_set_accumulators(isingmc_batch *b, const uint64_t *in) {
+    if (!b || !in) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    HIP_TRY(b, hipMemcpy(b->dev.acc, in, sizeof(uint64_t) * 8 * b->acc_rows, hipMemcpyHostToDevice));
+    return ISINGMC_OK;
+}
+int isingmc_clear_errors(isingmc_batch *b) {
+    if (!b) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    HIP_TRY(b, hipMemset(b->dev.err, 0, sizeof(uint32_t) * b->dev.R));
+    b->err.clear();
     return ISINGMC_OK;
 }
 int isingmc_reset_accumulators(isingmc_batch *b) {
@@ -899,6 +964,7 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
     if (nwords > cur) HIP_TRY(b, hipMemcpy(b->dev.cutoff + r, &nwords, 4, hipMemcpyHostToDevice));
     HIP_TRY(b, hipMemcpy(b->dev.n + r, &n, 4, hipMemcpyHostToDevice));
     HIP_TRY(b, hipMemcpy(b->dev.ntrans + r, &ntr, 4, hipMemcpyHostToDevice));
+    { const uint32_t zero = 0; HIP_TRY(b, hipMemcpy(b->dev.err + r, &zero, 4, hipMemcpyHostToDevice)); } // a fresh op-string: the replica's sticky error flag no longer applies
     if (ntr > b->max_ntrans) b->max_ntrans = ntr;
     HIP_TRY(b, hipMemcpy(b->dev.chunks + (size_t)r * 2 * SSE_MAX_CHUNKS, chunks.data(), sizeof(uint32_t) * chunks.size(), hipMemcpyHostToDevice));
     return ISINGMC_OK;
@@ -982,7 +1048,7 @@ int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->CL; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8); out[7] = (uint32_t)((4 * (b->lds_fixed_words_ - ((size_t)b->W * b->dev.N + 1) / 2) + 7) & ~(size_t)7);
+    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
     return ISINGMC_OK;
 }
 

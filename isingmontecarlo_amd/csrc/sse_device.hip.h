@@ -57,6 +57,8 @@ struct DevBatch {
     uint32_t *chunks;     // [R][2*SSE_MAX_CHUNKS]: per chunk of CH slots: occupied count, transverse-op count
     uint32_t CH, nchunks; // chunk size (multiple of 256 slots) and number of chunks covering cap
     uint32_t *uf_scratch; // [R][W*N+cap (+bit arrays)] union-find fallback in HBM
+    uint8_t *tbl;         // [R][tbl_stride] per-variable tables in HBM/L2 for models whose tables exceed LDS (MODE 2, see Tab)
+    uint32_t tbl_stride;  // bytes per replica: Wmax*N*2 (cut ranks / spin bytes) + Wmax*N (cut markers) + N (touched), rounded up to 16
     uint32_t seed_lo, seed_hi, replica_offset;
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
     uint32_t lds_words;   // dynamic LDS words available to the workgroup
@@ -207,10 +209,11 @@ struct Lds {           // word offsets into lds_raw
     uint32_t o_frozen; // [ufwords]     bit per id: segment holds a longitudinal op
     uint32_t o_froot;  // [ufwords]     bit per id: root is frozen
     uint32_t o_parent; // [ufcap] u16 (the LDS union-find is only used when every id fits 16 bits)
-    __device__ __forceinline__ void carve(uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges, uint32_t has_long) {
+    __device__ __forceinline__ void carve(uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges, uint32_t has_long, bool tg = false) {
         uint32_t base = 0;
         o_state = base; base += nwords;
         o_touch = base; base += nwords;
+        if (tg) N = 0; // MODE 2: the per-variable tables live in HBM (Tab<true>), only the bit arrays stay in LDS
         o_touch8 = base; base += (N + 3) / 4;
         o_tot = base; base += 2 * W;
         o_chg = base; base += 2 * W;
@@ -225,6 +228,42 @@ struct Lds {           // word offsets into lds_raw
         o_parent = base;
     }
 };
+// Per-variable tables of the ordered scans (spin bytes of the diagonal pass, cut ranks / cut markers / touched bytes of the
+// cluster scan).  TG = false: LDS (ds_* instructions, `reg` = word offset into lds_raw).  TG = true: a per-replica scratch in
+// HBM, in practice served by L2 / Infinity Cache (`reg` = byte offset into g) — for models whose tables exceed the 160 KB of
+// LDS (N >~ 10^4 variables, BASELINE configs[4] at 32^3).  A wave's own table is only touched by that wave between two
+// barriers, and global accesses of one wave are ordered at wavefront scope without waits, so the code is the same in both
+// modes; other waves' tables are only changed by atomics separated from their owners' accesses by a workgroup barrier.
+template <bool TG>
+struct Tab {
+    uint8_t *g;
+    uint32_t cur, cl, touch8;
+    __device__ __forceinline__ uint32_t ld8(uint32_t reg, uint32_t i) const { if constexpr (TG) return g[reg + i]; else return LDSB(reg, i); }
+    __device__ __forceinline__ void st8(uint32_t reg, uint32_t i, uint32_t v) const { if constexpr (TG) g[reg + i] = (uint8_t)v; else LDSB(reg, i) = (uint8_t)v; }
+    __device__ __forceinline__ uint32_t ld16(uint32_t reg, uint32_t i) const { if constexpr (TG) return reinterpret_cast<const uint16_t *>(g + reg)[i]; else return LDSH(reg, i); }
+    __device__ __forceinline__ void st16(uint32_t reg, uint32_t i, uint32_t v) const { if constexpr (TG) reinterpret_cast<uint16_t *>(g + reg)[i] = (uint16_t)v; else LDSH(reg, i) = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t ld32(uint32_t reg, uint32_t i) const { if constexpr (TG) return reinterpret_cast<const uint32_t *>(g + reg)[i]; else return LDSW(reg, i); }
+    __device__ __forceinline__ void st32(uint32_t reg, uint32_t i, uint32_t v) const { if constexpr (TG) reinterpret_cast<uint32_t *>(g + reg)[i] = v; else LDSW(reg, i) = v; }
+    __device__ __forceinline__ void xor32(uint32_t reg, uint32_t i, uint32_t bits) const {
+        if constexpr (TG) __hip_atomic_fetch_xor(reinterpret_cast<uint32_t *>(g + reg) + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else atomicXor(&LDSW(reg, i), bits);
+    }
+};
+template <bool TG, int W>
+__device__ __forceinline__ Tab<TG> make_tab(const DevBatch &B, const Lds<W> &L, uint32_t r) {
+    Tab<TG> T;
+    if constexpr (TG) {
+        T.g = B.tbl + (size_t)r * B.tbl_stride;
+        T.cur = 0u; T.cl = (uint32_t)W * B.N * 2u; T.touch8 = (uint32_t)W * B.N * 3u; // byte offsets (N is a multiple of 4 in this mode)
+    } else {
+        T.g = nullptr;
+        T.cur = L.o_cur; T.cl = L.o_cl; T.touch8 = L.o_touch8;
+    }
+    return T;
+}
+// MODE of a kernel: how bonds are decoded and where the per-variable tables live
+enum { SSE_MODE_GENERAL = 0, SSE_MODE_LDS_EDGES = 1, SSE_MODE_GLOBAL_TABLES = 2 };
+
 enum { MISC_NCLUST = 0, MISC_ANYFROZEN = 1, MISC_LOOP_A = 2, MISC_LOOP_B = 3, MISC_LOOP_C = 4, MISC_LOOP_D = 5 };
 
 template <bool CL, int W>
@@ -310,10 +349,11 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int 
 // Per slot and round the work is: one int->f64 convert, one f64 multiply, two f64 compares (written straight to
 // wave masks), the mask algebra on the scalar unit, and four mbcnt for the prefix counts.  All compares are the
 // IEEE f64 expressions of oracle/sse_oracle.c (built with -ffp-contract=off on both sides).
-template <int W, int K, bool CL, bool HB>
+template <int W, int K, bool CL, bool HB, bool TG>
 __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double beta, uint32_t M,
                               int &n_io, int &ntrans_io, uint32_t &gr) {
     constexpr int NT = W * 64;
+    const Tab<TG> T = make_tab<TG, W>(B, L, r);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     const double beta_nb = beta * (double)B.Nb;
@@ -333,7 +373,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
     const uint32_t N = B.N, h_my = (uint32_t)wave * N;
     for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) {
         const uint32_t v = i % N;
-        LDSB(L.o_cur, i) = (uint8_t)((LDSW(L.o_state, v >> 5) >> (v & 31)) & 1u);
+        T.st8(T.cur, i, (LDSW(L.o_state, v >> 5) >> (v & 31)) & 1u);
     }
     __syncthreads();
 
@@ -363,17 +403,17 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
 #pragma unroll
             for (int j = 0; j < K; ++j) { widx[j] = var[j] >> 2; bit[j] = 1u << ((var[j] & 3u) * 8u); }
             for (int w2 = wlo; w2 < whi; ++w2) {
-                const uint32_t tbl = L.o_cur + (uint32_t)w2 * (N >> 2);
+                const uint32_t tbl = (uint32_t)w2 * (N >> 2); // word index of wave w2's table inside the region
 #pragma unroll
                 for (int j = 0; j < K; ++j)
-                    if (ev[j]) atomicXor(&LDSW(tbl, widx[j]), bit[j]);
+                    if (ev[j]) T.xor32(T.cur, tbl + widx[j], bit[j]);
             }
         } else {
             for (int w2 = wlo; w2 < whi; ++w2) {
                 const uint32_t base = (uint32_t)w2 * N;
 #pragma unroll
                 for (int j = 0; j < K; ++j)
-                    if (ev[j]) spin_table_flip(L.o_cur, base + var[j]);
+                    if (ev[j]) T.xor32(T.cur, (base + var[j]) >> 2, 1u << (((base + var[j]) & 3u) * 8u));
             }
         }
     };
@@ -507,11 +547,11 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             // events on one variable inside a sub-round are rare; a serial loop over the event lanes handles them.
             const uint64_t ev0 = SSE_DBG(B, 16u) ? 0ull : sse_ballot(isev);
             if (ev0) {
-                if (flipa) LDSB(L.o_cur, h_my + va) = (uint8_t)((((uint32_t)lane + 1u) << 1) | inb);
-                if (flipc) LDSB(L.o_cur, h_my + vc) = (uint8_t)((((uint32_t)lane + 1u) << 1) | inc);
+                if (flipa) T.st8(T.cur, h_my + va, (((uint32_t)lane + 1u) << 1) | inb);
+                if (flipc) T.st8(T.cur, h_my + vc, (((uint32_t)lane + 1u) << 1) | inc);
                 SSE_WAVE_FENCE();
             }
-            const uint32_t ea = LDSB(L.o_cur, h_my + va), ec = LDSB(L.o_cur, h_my + vc);
+            const uint32_t ea = T.ld8(T.cur, h_my + va), ec = T.ld8(T.cur, h_my + vc);
             uint32_t sa = ea & 1u, sc = ec & 1u;
             if (ev0) {
                 const uint32_t La = ea >> 1, Lc = ec >> 1;
@@ -520,8 +560,8 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                     sa ^= (uint32_t)((La - 1u) < (uint32_t)lane); // La == 0: no event on the variable
                     sc ^= (uint32_t)((Lc - 1u) < (uint32_t)lane);
                     SSE_WAVE_FENCE();
-                    if (flipa) LDSB(L.o_cur, h_my + va) = (uint8_t)(inb ^ 1u);
-                    if (flipc) LDSB(L.o_cur, h_my + vc) = (uint8_t)(inc ^ 1u);
+                    if (flipa) T.st8(T.cur, h_my + va, inb ^ 1u);
+                    if (flipc) T.st8(T.cur, h_my + vc, inc ^ 1u);
                 } else {
                     bool seen_a = false, seen_c = false;
                     uint64_t m = ev0;
@@ -537,7 +577,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                             const uint32_t inL = __builtin_amdgcn_readlane(which ? inc : inb, Ls);
                             if (va == vL) { sa = later ? (inL ^ 1u) : (seen_a ? sa : inL); seen_a = true; }
                             if (vc == vL) { sc = later ? (inL ^ 1u) : (seen_c ? sc : inL); seen_c = true; }
-                            if (lane == Ls) LDSB(L.o_cur, h_my + vL) = (uint8_t)(inL ^ 1u); // in order: the last event wins
+                            if (lane == Ls) T.st8(T.cur, h_my + vL, inL ^ 1u); // in order: the last event wins
                         }
                     }
                     SSE_WAVE_FENCE();
@@ -774,18 +814,19 @@ __device__ __forceinline__ void uf_union_wave(const UFA<false> &uf, uint32_t a, 
 //   [N+C, N+C+(W-1)N)     P(w,v): "whatever segment v is in when wave w's range begins" — artificial ids, larger
 //                                 than every real id so they are never roots; joined to the real segments after
 //                                 the scan (cluster_pass).
-template <int W, int K, bool CL, bool APPLY, bool G>
+template <int W, int K, bool CL, bool APPLY, bool G, bool TG>
 __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<G> &uf,
                                              uint32_t C) {
     constexpr int NT = W * 64;
+    const Tab<TG> T = make_tab<TG, W>(B, L, r);
     constexpr uint32_t TS = 64 * K; // slots per wave-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t N = B.N;
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     uint32_t *segs_row = B.segs + (size_t)r * B.stride;
     const uint32_t h_mycur = (uint32_t)wave * N; // element offset of this wave's tables inside o_cur / o_cl
-    for (uint32_t i = tid; i < ((uint32_t)W * N + 1) / 2; i += NT) LDSW(L.o_cur, i) = 0u;
-    for (uint32_t i = tid; i < ((uint32_t)W * N + 3) / 4; i += NT) LDSW(L.o_cl, i) = 0u;
+    for (uint32_t i = tid; i < ((uint32_t)W * N + 1) / 2; i += NT) T.st32(T.cur, i, 0u);
+    for (uint32_t i = tid; i < ((uint32_t)W * N + 3) / 4; i += NT) T.st32(T.cl, i, 0u);
     __syncthreads();
     // this wave's chunk range and the dense id of its first cut
     const uint32_t used = (M + B.CH - 1) / B.CH;
@@ -844,11 +885,11 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             // earlier cuts.  Two cuts of one sub-round on the same variable are rare: a serial loop over the cut
             // lanes (ballot + v_readlane) resolves those.
             if (cutmask) {
-                if (iscut) LDSB(L.o_cl, h_mycur + va) = (uint8_t)(kown + 1u);
+                if (iscut) T.st8(T.cl, h_mycur + va, kown + 1u);
                 SSE_WAVE_FENCE();
             }
-            const uint32_t xa = LDSH(L.o_cur, h_mycur + va), xc = LDSH(L.o_cur, h_mycur + vc);
-            const uint32_t ma = LDSB(L.o_cl, h_mycur + va), mc = LDSB(L.o_cl, h_mycur + vc);
+            const uint32_t xa = T.ld16(T.cur, h_mycur + va), xc = T.ld16(T.cur, h_mycur + vc);
+            const uint32_t ma = T.ld8(T.cl, h_mycur + va), mc = T.ld8(T.cl, h_mycur + vc);
             uint32_t seg_a = xa ? idbase + xa : my_placeholder_base + va;
             uint32_t seg_c = xc ? idbase + xc : my_placeholder_base + vc;
             if (cutmask) {
@@ -858,7 +899,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                     seg_a = ((ma - 1u) < kown) ? first + (ma - 1u) : seg_a; // ma == 0: no cut on the variable
                     seg_c = ((mc - 1u) < kown) ? first + (mc - 1u) : seg_c;
                     SSE_WAVE_FENCE();
-                    if (iscut) { LDSH(L.o_cur, h_mycur + va) = (uint16_t)myrank1; LDSB(L.o_cl, h_mycur + va) = (uint8_t)0; }
+                    if (iscut) { T.st16(T.cur, h_mycur + va, myrank1); T.st8(T.cl, h_mycur + va, 0u); }
                 } else {
                     bool lastcut = iscut; // no later cut lane of this sub-round is on the same variable
                     uint64_t m = cutmask;
@@ -874,14 +915,14 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                         idL++;
                     }
                     SSE_WAVE_FENCE();
-                    if (iscut) LDSB(L.o_cl, h_mycur + va) = (uint8_t)0;
-                    if (iscut & lastcut) LDSH(L.o_cur, h_mycur + va) = (uint16_t)myrank1; // the last cut wins
+                    if (iscut) T.st8(T.cl, h_mycur + va, 0u);
+                    if (iscut & lastcut) T.st16(T.cur, h_mycur + va, myrank1); // the last cut wins
                 }
             }
             nlocal += popc64(cutmask);
             if (!APPLY) {
                 if (iscut) uf.set(id_own, id_own);
-                if (nonempty) { LDSB(L.o_touch8, va) = (uint8_t)1; LDSB(L.o_touch8, vc) = (uint8_t)1; }
+                if (nonempty) { T.st8(T.touch8, va, 1u); T.st8(T.touch8, vc, 1u); }
                 ua[j] = seg_a; uc[j] = seg_c;
                 utwo[j] = two & !SSE_DBG(B, 1u); // diagnostic builds: bit 0 = time the scan without unions
                 if (B.has_long) if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
@@ -994,10 +1035,12 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
 
 // Cluster update.  Reference: ClusterUpdater::flip_each_cluster_rng (qmc_traits/cluster.rs:36-172) with the
 // longitudinal weight function of qmc_ising.rs:759-775.  Returns the number of clusters.
-template <int W, int K, bool CL, bool UF_GLOBAL>
+template <int W, int K, bool CL, bool UF_GLOBAL, bool TG>
 __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double prob,
                                                  uint32_t M, int n, int ntrans, uint32_t &gr, uint32_t &err) {
+    static_assert(UF_GLOBAL || !TG, "tables in HBM imply the HBM union-find");
     constexpr int NT = W * 64;
+    const Tab<TG> T = make_tab<TG, W>(B, L, r);
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t N = B.N, nwords = B.nwords;
     UFA<UF_GLOBAL> uf;
@@ -1009,7 +1052,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
         uf.o_parent = L.o_parent; uf.o_frozen = L.o_frozen; uf.o_froot = L.o_froot;
     }
     for (uint32_t i = tid; i < nwords; i += NT) LDSW(L.o_touch, i) = 0u;
-    for (uint32_t i = tid; i < (N + 3) / 4; i += NT) LDSW(L.o_touch8, i) = 0u;
+    for (uint32_t i = tid; i < (N + 3) / 4; i += NT) T.st32(T.touch8, i, 0u);
     if (tid == 0) { LDSW(L.o_misc, MISC_NCLUST) = 0u; LDSW(L.o_misc, MISC_ANYFROZEN) = 0u; }
     if (n == 0) { __syncthreads(); return 0u; } // cluster.rs:46-48
     SSE_STAMP_INIT;
@@ -1031,12 +1074,12 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     __syncthreads();
     // ---- build: label legs with segment ids, union through non-boundary ops ----
     SSE_STAMP(0);
-    cluster_scan<W, K, CL, false, UF_GLOBAL>(B, L, r, M, uf, C);
+    cluster_scan<W, K, CL, false, UF_GLOBAL, TG>(B, L, r, M, uf, C);
     // touched bytes -> bits (read by the coins, the p=0 state update and the free-spin pass, all behind later barriers)
     for (uint32_t i = tid; i < nwords; i += NT) {
         uint32_t bits = 0;
         for (uint32_t k = 0; k < 8 && (i * 8 + k) < (N + 3) / 4; ++k) {
-            const uint32_t w = LDSW(L.o_touch8, i * 8 + k);
+            const uint32_t w = T.ld32(T.touch8, i * 8 + k);
             bits |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * k);
         }
         LDSW(L.o_touch, i) = bits;
@@ -1046,7 +1089,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     // range wraps around into P(0,v) (cluster.rs:223-242: worldlines are cyclic in imaginary time)
     for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) {
         const uint32_t w2 = i / N, v = i - w2 * N;
-        const uint32_t x = LDSH(L.o_cur, i);
+        const uint32_t x = T.ld16(T.cur, i);
         const uint32_t last = x ? LDSW(L.o_chg, w2) + x : 0u;
         const uint32_t seg_end = last ? last : (w2 == 0 ? v : N + C + (w2 - 1) * N + v);
         const uint32_t nxt = (w2 + 1 == (uint32_t)W) ? v : N + C + w2 * N + v;
@@ -1140,7 +1183,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     __syncthreads();
     SSE_STAMP(4);
     // ---- apply (cluster.rs:139-167) ----
-    if constexpr (UF_GLOBAL) cluster_scan<W, K, CL, true, UF_GLOBAL>(B, L, r, M, uf, C);
+    if constexpr (UF_GLOBAL) cluster_scan<W, K, CL, true, UF_GLOBAL, TG>(B, L, r, M, uf, C);
     else cluster_apply_cached<W, K, CL>(B, L, r, M, uf);
     SSE_STAMP(5);
     // p=0 state follows the placeholder segment of each touched variable
@@ -1261,7 +1304,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
         side0 = (o0.z >> 31) ? 0u : 1u; // gen() true -> Inputs (directed_loop.rs:153-157)
     }
     uint32_t p = p0, rel = rel0, side = side0, visited = 0;
-    const uint32_t max_steps = 8u * M + 64u;
+    const uint32_t max_steps = 64u * M + 1024u; // the reference's loop is unbounded (directed_loop.rs:217-301); past this the replica reports ISINGMC_ELIMIT (clearable)
     bool finished = false;
     for (uint32_t step = 1; step <= max_steps; ++step) {
         // ---- vertex update by thread 0 ----
@@ -1376,11 +1419,12 @@ constexpr int sse_waves_per_simd() {
     if (PASSES == SSE_PASSES_DIAG) return W <= 4 ? 4 : (W <= 8 ? 2 : 1);
     return W == 8 ? SSE_MIN_WAVES_PER_SIMD : (W == 6 ? 3 : (W == 4 ? 2 : 1));
 }
-template <int W, int K, bool CL, int PHASE, int PASSES>
+template <int W, int K, int MODE, int PHASE, int PASSES>
 __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void sweep_kernel(DevBatch B, SweepArgs A) {
     constexpr int NT = W * 64;
+    constexpr bool CL = MODE == SSE_MODE_LDS_EDGES, TG = MODE == SSE_MODE_GLOBAL_TABLES;
     Lds<W> L;
-    L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u, B.has_long);
+    L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u, B.has_long, TG);
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
     if (B.bond_stride) { // per-replica couplings: this replica's tables (B is this workgroup's private copy)
@@ -1403,8 +1447,8 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         if constexpr (PASSES != SSE_PASSES_OFFDIAG)
         if (A.domask & SSE_DO_DIAG) {
             const Rng rng = make_rng(B, r, epoch);
-            if (A.domask & SSE_DO_HEATBATH) diagonal_pass<W, K, CL, true>(B, L, r, rng, beta, M, n, ntrans, gr);
-            else diagonal_pass<W, K, CL, false>(B, L, r, rng, beta, M, n, ntrans, gr);
+            if (A.domask & SSE_DO_HEATBATH) diagonal_pass<W, K, CL, true, TG>(B, L, r, rng, beta, M, n, ntrans, gr);
+            else diagonal_pass<W, K, CL, false, TG>(B, L, r, rng, beta, M, n, ntrans, gr);
             epoch++;
             a5 += M;
             if (A.domask & SSE_DO_GROW) { // qmc_ising.rs:786, qmc_runner.rs:197
@@ -1412,7 +1456,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
                 if (want > M) { if (want > B.cap) { err = 1u; break; } M = want; }
             }
         }
-        if constexpr (PASSES == SSE_PASSES_ALL)
+        if constexpr (PASSES == SSE_PASSES_ALL && !TG) // (RVB keeps its working set in LDS: refused by the host for MODE 2 models)
         if (A.domask & SSE_DO_RVB) { // qmc_ising.rs:705-752
             const uint32_t updates = A.rvb_updates ? A.rvb_updates : (B.N + 1u) / 2u;
             last_out = rvb_pass<W, CL>(B, L, r, epoch, M, updates, gr, err);
@@ -1433,8 +1477,9 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         if (A.domask & SSE_DO_CLUSTER) {
             const Rng rng = make_rng(B, r, epoch);
             const uint32_t S_ids = (uint32_t)W * B.N + (uint32_t)ntrans;
-            if (S_ids <= B.lds_ufcap && S_ids <= 65535u) last_out = cluster_pass<W, K, CL, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
-            else last_out = cluster_pass<W, K, CL, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+            if constexpr (TG) last_out = cluster_pass<W, K, CL, true, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+            else if (S_ids <= B.lds_ufcap && S_ids <= 65535u) last_out = cluster_pass<W, K, CL, false, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+            else last_out = cluster_pass<W, K, CL, true, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             epoch++;
             a4 += (uint64_t)n;
             if (err) break;
@@ -1472,7 +1517,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
 }
 
 struct LaunchCfg {
-    uint32_t W, K, CL, phase, passes;
+    uint32_t W, K, mode, phase, passes; // mode: SSE_MODE_*
     size_t lds_bytes;
     hipStream_t stream;
 };
@@ -1483,7 +1528,7 @@ hipError_t launch_sweep_w6(const LaunchCfg &c, const DevBatch &B, const SweepArg
 hipError_t launch_sweep_w8(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_w16(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 
-template <int W, int K, bool CL, int PHASE, int PASSES>
+template <int W, int K, int CL, int PHASE, int PASSES>
 hipError_t launch_one(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel<W, K, CL, PHASE, PASSES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_bytes);
@@ -1491,7 +1536,7 @@ hipError_t launch_one(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A)
     hipLaunchKernelGGL((sweep_kernel<W, K, CL, PHASE, PASSES>), dim3(B.R), dim3(W * 64), c.lds_bytes, c.stream, B, A);
     return hipGetLastError();
 }
-template <int W, int K, bool CL>
+template <int W, int K, int CL>
 hipError_t launch_k(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
     if (c.passes == SSE_PASSES_DIAG) {
         if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_DIAG>(c, B, A);
@@ -1506,12 +1551,18 @@ hipError_t launch_k(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
 }
 template <int W>
 hipError_t launch_w(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
-    if (c.K == 4 && c.CL) return launch_k<W, 4, true>(c, B, A);
-    if (c.K == 4 && !c.CL) return launch_k<W, 4, false>(c, B, A);
-    if (c.K == 1 && c.CL) return launch_k<W, 1, true>(c, B, A);
-    if (c.K == 1 && !c.CL) return launch_k<W, 1, false>(c, B, A);
-    if (c.K == 2 && c.CL) return launch_k<W, 2, true>(c, B, A);
-    if (c.K == 2 && !c.CL) return launch_k<W, 2, false>(c, B, A);
+    if (c.mode == SSE_MODE_GLOBAL_TABLES) { // tables in HBM: slots_per_lane 4 and 1 only
+        if (c.K == 4) return launch_k<W, 4, SSE_MODE_GLOBAL_TABLES>(c, B, A);
+        if (c.K == 1) return launch_k<W, 1, SSE_MODE_GLOBAL_TABLES>(c, B, A);
+        return hipErrorInvalidValue;
+    }
+    const bool cl = c.mode == SSE_MODE_LDS_EDGES;
+    if (c.K == 4 && cl) return launch_k<W, 4, SSE_MODE_LDS_EDGES>(c, B, A);
+    if (c.K == 4 && !cl) return launch_k<W, 4, SSE_MODE_GENERAL>(c, B, A);
+    if (c.K == 1 && cl) return launch_k<W, 1, SSE_MODE_LDS_EDGES>(c, B, A);
+    if (c.K == 1 && !cl) return launch_k<W, 1, SSE_MODE_GENERAL>(c, B, A);
+    if (c.K == 2 && cl) return launch_k<W, 2, SSE_MODE_LDS_EDGES>(c, B, A);
+    if (c.K == 2 && !cl) return launch_k<W, 2, SSE_MODE_GENERAL>(c, B, A);
     return hipErrorInvalidValue;
 }
 

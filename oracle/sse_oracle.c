@@ -115,6 +115,29 @@ ora_model *ora_model_create_generic(uint32_t nvars, uint32_t nbonds, const uint3
     m->offset = offset;
     return m;
 }
+/* Interaction::at (qmc_runner.rs:573-612) with index_from_state (:666-679): index = outputs then inputs, every bit
+ * list MSB first; a Diagonal interaction (kind 1) holds only its 2^k diagonal and is 0 elsewhere (:594-610). */
+double ora_interaction_at(uint32_t k, uint32_t diagonal, const double *mat, const uint8_t *inputs, const uint8_t *outputs) {
+    size_t idx = 0;
+    if (diagonal) {
+        for (uint32_t i = 0; i < k; ++i) if ((inputs[i] != 0) != (outputs[i] != 0)) return 0.0;
+        for (uint32_t i = 0; i < k; ++i) idx = (idx << 1) | (inputs[i] ? 1u : 0u);
+        return mat[idx];
+    }
+    for (uint32_t i = 0; i < k; ++i) idx = (idx << 1) | (outputs[i] ? 1u : 0u);
+    for (uint32_t i = 0; i < k; ++i) idx = (idx << 1) | (inputs[i] ? 1u : 0u);
+    return mat[idx];
+}
+/* Interaction::sym_under_ising (qmc_runner.rs:639-664), index ranges exactly as written there */
+int ora_interaction_sym_under_ising(uint32_t k, uint32_t diagonal, const double *mat) {
+    const size_t mask = diagonal ? (((size_t)1 << k) - 1) : (((size_t)1 << (2 * k)) - 1);
+    const size_t upto = diagonal ? ((size_t)1 << (k >> 1)) : ((size_t)1 << k);
+    for (size_t i = 0; i < upto; ++i) {
+        const double d = mat[i] - mat[(~i) & mask];
+        if (!((d < 0 ? -d : d) < 2.220446049250313e-16)) return 0;
+    }
+    return 1;
+}
 void ora_model_destroy(ora_model *m) {
     if (!m) return;
     free(m->bond_a); free(m->bond_b); free(m->binfo); free(m->bweight); free(m->cumw); free(m->mats); free(m);

@@ -38,6 +38,9 @@ ora_model *ora_model_create(uint32_t nvars, uint32_t nedges, const uint32_t *edg
 /* generic 1- and 2-variable interactions (qmc_runner.rs:415-680); mats[b][in | out<<2] */
 ora_model *ora_model_create_generic(uint32_t nvars, uint32_t nbonds, const uint32_t *k, const uint32_t *var_a,
                                     const uint32_t *var_b, const double *mats, double offset);
+/* Interaction::at / sym_under_ising (qmc_runner.rs:573-612,639-664): mat is [4^k], or [2^k] when diagonal != 0 */
+double ora_interaction_at(uint32_t k, uint32_t diagonal, const double *mat, const uint8_t *inputs, const uint8_t *outputs);
+int ora_interaction_sym_under_ising(uint32_t k, uint32_t diagonal, const double *mat);
 void ora_model_destroy(ora_model *m);
 uint32_t ora_model_nbonds(const ora_model *m);
 double ora_model_offset(const ora_model *m);

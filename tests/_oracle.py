@@ -58,6 +58,8 @@ def load():
         "ora_rvb_update": (u32, [vp, u32]),
         "ora_find_overlapping_starts": (u32, [u32, u32, u32, p(u32), u32, p(u32)]),
         "ora_remove_doubles": (u32, [p(u32), u32]),
+        "ora_interaction_at": (f64, [u32, u32, p(f64), p(C.c_uint8), p(C.c_uint8)]),
+        "ora_interaction_sym_under_ising": (C.c_int, [u32, u32, p(f64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -82,6 +84,18 @@ def _ptr(a, t):
 
 def op_make(bond, in_bits, out_bits):
     return ((bond + 1) << 4) | (in_bits & 3) | ((out_bits & 3) << 2)
+
+
+def interaction_at(mat, inputs, outputs):
+    m = np.ascontiguousarray(np.asarray(mat, dtype=np.float64))
+    k = len(inputs)
+    i = np.ascontiguousarray(np.asarray(inputs, dtype=np.uint8)); o = np.ascontiguousarray(np.asarray(outputs, dtype=np.uint8))
+    return lib().ora_interaction_at(k, 1 if len(m) == 2 ** k else 0, _ptr(m, C.c_double), _ptr(i, C.c_uint8), _ptr(o, C.c_uint8))
+
+
+def interaction_sym_under_ising(mat, k):
+    m = np.ascontiguousarray(np.asarray(mat, dtype=np.float64))
+    return bool(lib().ora_interaction_sym_under_ising(k, 1 if len(m) == 2 ** k else 0, _ptr(m, C.c_double)))
 
 
 class Model:
@@ -109,15 +123,10 @@ class Model:
         for i, (mat, vs) in enumerate(interactions):
             mat = np.asarray(mat, dtype=np.float64)
             ks[i] = len(vs); va[i] = vs[0]; vb[i] = vs[1] if len(vs) == 2 else 0
-            if len(vs) == 2:
-                for i_ in range(4):
-                    for o_ in range(4):
-                        ref = ((o_ & 1) << 3) | (((o_ >> 1) & 1) << 2) | ((i_ & 1) << 1) | ((i_ >> 1) & 1)
-                        mats[i, i_ | (o_ << 2)] = mat[ref]
-            else:
-                for i_ in range(2):
-                    for o_ in range(2):
-                        mats[i, i_ | (o_ << 2)] = mat[(o_ << 1) | i_]
+            kk = len(vs)
+            for i_ in range(1 << kk):  # oracle layout: bit 0 = first variable
+                for o_ in range(1 << kk):
+                    mats[i, i_ | (o_ << 2)] = interaction_at(mat, [(i_ >> j) & 1 for j in range(kk)], [(o_ >> j) & 1 for j in range(kk)])
         self.gamma = self.h = 0.0
         self.ptr = lib().ora_model_create_generic(self.nvars, nb, _ptr(ks, C.c_uint32), _ptr(va, C.c_uint32), _ptr(vb, C.c_uint32),
                                                   _ptr(np.ascontiguousarray(mats), C.c_double), float(offset))

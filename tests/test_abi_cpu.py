@@ -30,7 +30,7 @@ def test_header_symbols_are_exported_and_bound():
 def test_config_struct_layout_matches_header():
     import isingmontecarlo_amd as im
     # 4 u32, 2 pointers, 2 doubles, 2 u32, u64, u32, i32, pointer, 5 u32 (+4 padding), pointer, u32 (+4), double -> 128 bytes on LP64
-    assert C.sizeof(im._Config) == 128
+    assert C.sizeof(im._Config) == 128 and C.sizeof(im._Interaction) == 24 and im._Interaction.mat.offset == 16
     assert im._Config.seed.offset == 56 and im._Config.init_state.offset == 72
 
 
@@ -74,6 +74,37 @@ def test_create_rejects_bad_generic_interactions():
         im.Qmc.from_interactions(2, [(np.ones(4), (0, 1))], 4, 1)
     m, off = im.Qmc.interaction_and_offset([3.0, 1.0, 1.0, 2.0])  # Interaction::new_offset: diagonal minimum removed
     assert off == 2.0 and np.allclose(m, [1.0, 1.0, 1.0, 0.0])
+
+
+def test_create_argument_checks_that_need_no_device():
+    """capacity == 0 (would divide by zero in the chunk grid) and interactions on more than two variables."""
+    import isingmontecarlo_amd as im
+    lib = im.load_library()
+    h = C.c_void_p()
+    ed = np.array([0, 1], dtype=np.uint32); js = np.array([1.0])
+    cfg = im._Config(struct_size=C.sizeof(im._Config), nreplicas=1, nvars=2, nedges=1,
+                     edges=ed.ctypes.data_as(C.POINTER(C.c_uint32)), J=js.ctypes.data_as(C.POINTER(C.c_double)),
+                     transverse=1.0, capacity=0, cutoff0=0, device=-1)
+    assert lib.isingmc_create(C.byref(cfg), C.byref(h)) == -1 and b"capacity" in lib.isingmc_last_error(None)
+    mat = np.ones(64)
+    it = im._Interaction(nvars=3, mat=mat.ctypes.data_as(C.POINTER(C.c_double)))
+    cfg = im._Config(struct_size=C.sizeof(im._Config), nreplicas=1, nvars=3, capacity=8, cutoff0=4, device=-1,
+                     interactions=C.cast(C.pointer(it), C.c_void_p), ninteractions=1)
+    assert lib.isingmc_create(C.byref(cfg), C.byref(h)) == -5  # ENOTIMPL, qmc_runner.rs:415-680 allows any k
+    with pytest.raises(im.IsingMcError) as ei:
+        im.Qmc.from_interactions(3, [(np.ones(64), (0, 1, 2))], 4, 1)
+    assert ei.value.code == -5
+    assert lib.isingmc_clear_errors(None) == -1 and lib.isingmc_set_accumulators(None, None) == -1
+
+
+def test_into_qmc_moves_the_handle_without_a_device():
+    """Advisor finding r1: into_qmc used to share one __dict__ and null the handle of BOTH objects."""
+    import isingmontecarlo_amd as im
+    g = im.QmcIsingGraph.__new__(im.QmcIsingGraph)
+    g._lib, g._h, g._flags, g.nreplicas = None, 12345, im.FLAG_HEATBATH, 1
+    q = g.into_qmc(do_loop_updates=True)
+    assert q._h == 12345 and g._h is None and q._flags == (im.FLAG_HEATBATH | im.FLAG_LOOP)
+    q._h = None  # nothing real to destroy
 
 
 def test_null_handle_calls_do_not_crash():

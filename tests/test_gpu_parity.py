@@ -430,3 +430,171 @@ def test_variable_autocorrelation_runs_on_sampled_states(oracle):
     assert_same(g, reps, "after autocorrelation sampling")
     pc = spin_product_autocorrelation(g, 32, 1.0, [(0, 1), (2, 3, 4)], r=1)
     assert pc.shape == (32,) and np.isfinite(pc).all() and 0.0 <= pc[0] <= 1.0 + 1e-9
+
+
+def test_bond_counts_match_the_oracle(oracle):
+    """OpContainer::get_count (op_container.rs:129; fast_ops.rs:1281-1294) for every bond, straight through isingmc_get_bond_count."""
+    edges = lat.one_d_periodic(6, -1.0)
+    R = 3
+    g, m, reps = make_pair(oracle, edges, 0.8, 0.3, 6, 1 << 11, 2718, R)
+    g.run(40, 2.5)
+    oracle.batch_timesteps(reps, 40, [2.5] * R)
+    assert g.num_bonds() == m.nbonds == 6 + 6 + 6
+    n = g.get_n()
+    for r, rep in enumerate(reps):
+        counts = [g.get_bond_count(b, r) for b in range(m.nbonds)]
+        assert counts == [rep.bond_count(b) for b in range(m.nbonds)]
+        assert sum(counts) == n[r] and max(counts) > 0
+
+
+def test_into_qmc_hands_the_batch_over(oracle):
+    """IntoQmc::into_qmc (qmc_ising.rs:943-976; tests/convert_test.rs): the converted object owns the live device batch and
+    continues the same Markov chain through Qmc::timestep (diagonal -> loop -> cluster -> free spins)."""
+    import isingmontecarlo_amd as im
+    edges = lat.one_d_periodic(8)
+    R = 4
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 8, 1 << 11, 1234, R)
+    g.run(10, 1.0)
+    q = g.into_qmc(do_loop_updates=True)
+    assert g._h is None and q._h is not None and isinstance(q, im.Qmc) and q.should_do_loop_update()
+    q.run(10, 1.0)
+    for rep in reps:
+        rep.timesteps(10, 1.0, 1, 0)
+        rep.timesteps(10, 1.0, 1, im.FLAG_LOOP)
+    assert_same(q, reps, "into_qmc")
+    assert q.verify().all()
+    g.close()  # the emptied source object must not free the batch it handed over
+    assert q.get_n().shape == (R,)
+
+
+def test_checkpoint_restores_accumulators_and_refuses_larger_cutoffs(oracle, tmp_path):
+    import isingmontecarlo_amd as im
+    edges = lat.two_d_periodic(4)
+    R = 3
+    g = im.QmcIsingGraph(edges, 1.0, 0.0, 16, 5, nreplicas=R, capacity=1 << 12)
+    g.run(20, 2.0, sampling_freq=2)
+    path = str(tmp_path / "c.npz")
+    g.save_checkpoint(path)
+    g2 = im.QmcIsingGraph(edges, 1.0, 0.0, 16, 5, nreplicas=R, capacity=1 << 12)
+    g2.load_checkpoint(path)
+    assert np.array_equal(g2.accumulators(), g.accumulators()) and g.accumulators()[:, 1].all()
+    g.run(7, 2.0, sampling_freq=2); g2.run(7, 2.0, sampling_freq=2)
+    assert np.array_equal(g2.accumulators(), g.accumulators())
+    big = im.QmcIsingGraph(edges, 1.0, 0.0, 4000, 5, nreplicas=R, capacity=1 << 12)  # larger cutoff than the saved one
+    with pytest.raises(im.IsingMcError):
+        big.load_checkpoint(path)
+
+
+def test_error_flags_are_sticky_until_cleared(oracle):
+    import isingmontecarlo_amd as im
+    g = im.QmcIsingGraph(lat.two_d_ferro(4), 1.0, 0.0, 16, 3, nreplicas=2, capacity=96)
+    with pytest.raises(im.IsingMcError) as ei:
+        g.run(60, 6.0)
+    assert ei.value.code == -3
+    with pytest.raises(im.IsingMcError):  # sticky: the replica stays parked
+        g.run(1, 0.1)
+    g.clear_errors()
+    g.run(1, 0.01)  # at a high temperature n + n/2 fits again
+
+
+def test_more_than_two_variables_is_a_loud_enotimpl():
+    """Interactions on k > 2 variables (qmc_runner.rs:415-680 allows any k) are refused loudly, never truncated."""
+    import ctypes as C
+    import isingmontecarlo_amd as im
+    with pytest.raises(im.IsingMcError) as ei:
+        im.Qmc.from_interactions(3, [(np.ones(64), (0, 1, 2))], 4, 1)
+    assert ei.value.code == -5
+    lib = im.load_library()
+    mat = np.ones(64)
+    it = im._Interaction(nvars=3, mat=mat.ctypes.data_as(C.POINTER(C.c_double)))
+    cfg = im._Config(struct_size=C.sizeof(im._Config), nreplicas=1, nvars=3, capacity=8, cutoff0=4, device=-1,
+                     interactions=C.cast(C.pointer(it), C.c_void_p), ninteractions=1)
+    h = C.c_void_p()
+    assert lib.isingmc_create(C.byref(cfg), C.byref(h)) == -5
+    assert b"more than two variables" in lib.isingmc_last_error(None)
+
+
+# ---- models whose per-variable tables live in HBM (ISINGMC_CFG_GLOBAL_TABLES; automatic for N >~ 10^4, BASELINE configs[4]) ----
+
+@pytest.mark.parametrize("waves,k,flags", [(4, 4, 0), (1, 1, 0), (8, 4, 1), (4, 1, 4), (16, 4, 5), (6, 4, 0)])
+@pytest.mark.parametrize("name,edges,gamma,h,beta", CASES, ids=[c[0] for c in CASES])
+def test_global_tables_path_matches_oracle(oracle, name, edges, gamma, h, beta, waves, k, flags):
+    """The HBM/L2-resident table path forced on small models: every pass combination against the oracle, bit for bit."""
+    import isingmontecarlo_amd as im
+    R = 4
+    g, m, reps = make_pair(oracle, edges, gamma, h, 8, 8192, 4321, R, waves, k=k,
+                           cfg_flags=im.CFG_GLOBAL_TABLES | im.CFG_NO_LDS_TABLES)
+    info = g.launch_info()
+    assert info["global_tables"] and not info["lds_edge_table"] and info["lds_uf_ids"] == 0
+    for it in range(3):  # primitives one by one ...
+        g.single_diagonal_step(beta)
+        for rep in reps:
+            rep.diagonal_update(beta)
+            want = rep.n + rep.n // 2
+            if want > rep.cutoff:
+                assert rep.set_cutoff(want) == 0
+        assert_same(g, reps, f"{name} TG diag it={it}")
+        nc = g.single_cluster_step(flip_free=True)
+        for r, rep in enumerate(reps):
+            assert nc[r] == rep.cluster_update(0.5)
+            rep.flip_free_spins()
+        assert_same(g, reps, f"{name} TG cluster it={it}")
+    g.run(30, beta, sampling_freq=2, flags=flags)  # ... and whole timesteps
+    for rep in reps:
+        rep.timesteps(30, beta, 2, flags)
+    assert_same(g, reps, f"{name} TG timesteps flags={flags}")
+    assert g.verify().all()
+    with pytest.raises(im.IsingMcError) as ei:
+        g.single_rvb_sweep()
+    assert ei.value.code == -5
+
+
+def test_global_tables_with_per_replica_couplings_and_generic_interactions(oracle):
+    """configs[4] in small through the HBM-table path: +-J cubic lattice, one disorder realisation per replica, h != 0;
+    and a generic-interaction model on the same path."""
+    import isingmontecarlo_amd as im
+    l, R = 4, 5
+    edges = lat.cubic_periodic(l)
+    rng = np.random.default_rng(99)
+    J = rng.choice([-1.0, 1.0], size=(R, len(edges)))
+    g = im.QmcIsingGraph(edges, 1.0, 0.1, 64, 777, nreplicas=R, capacity=1 << 13, couplings=J, cfg_flags=im.CFG_GLOBAL_TABLES)
+    assert g.launch_info()["global_tables"]
+    e = [ab for ab, _ in edges]
+    reps = [oracle.Replica(oracle.Model(g.nvars, e, list(J[r]), 1.0, 0.1), 1 << 13, 64, 777, r, None) for r in range(R)]
+    g.run(25, 2.0)
+    oracle.batch_timesteps(reps, 25, [2.0] * R)
+    assert_same(g, reps, "cubic +-J, tables in HBM")
+    assert g.verify().all()
+    n = 7
+    ints = lat.xxz_ring_interactions(n)
+    # (generic models take the general bond table by construction; cluster updates on: the model is Ising-symmetric)
+    q = im.Qmc.from_interactions(n, ints, 8, 31, nreplicas=3, capacity=1 << 12)
+    assert not q.launch_info()["global_tables"]
+
+
+def test_cubic_32_full_size_runs_on_the_global_tables_path(oracle):
+    """BASELINE configs[4] at its stated lattice size: 32^3 = 32768 variables, 98304 edges, per-replica +-J, Gamma = 1,
+    h = 0.1, beta = 4.  The per-variable tables (128 KB of spin bytes at 4 waves) do not fit LDS: the engine must pick the
+    HBM-table path by itself.  A few replicas are checked bit for bit against the oracle over the cutoff-growth phase,
+    and through the size-independent properties (verify, cutoff growth rule, energy sanity)."""
+    import isingmontecarlo_amd as im
+    l, R, beta, sweeps = 32, 4, 4.0, 12
+    edges = lat.cubic_periodic(l)
+    nsite = l ** 3
+    rng = np.random.default_rng(32768)
+    J = rng.choice([-1.0, 1.0], size=(R, len(edges)))
+    cap = 1 << 21
+    g = im.QmcIsingGraph(edges, 1.0, 0.1, nsite, 2026, nreplicas=R, capacity=cap, couplings=J)
+    info = g.launch_info()
+    assert g.nvars == nsite and info["global_tables"] and info["waves_per_replica"] == 4
+    e = [ab for ab, _ in edges]
+    reps = [oracle.Replica(oracle.Model(nsite, e, list(J[r]), 1.0, 0.1), cap, nsite, 2026, r, None) for r in range(R)]
+    g.run(sweeps, beta)
+    oracle.batch_timesteps(reps, sweeps, [beta] * R)
+    assert_same(g, reps, "32^3 +-J")
+    assert g.verify().all()
+    n, cut = g.get_n(), g.get_cutoff()
+    assert (cut >= n + n // 2).all() or (cut == cut.max()).all()  # qmc_ising.rs:786: cutoff = max(cutoff, n + n/2) after every sweep
+    assert (n > 5 * nsite).all() and (n < 40 * nsite).all()       # still growing towards beta * (offset - E0) ~ 4 * 6 per site
+    en = -(g.accumulators()[:, 0] / np.maximum(g.accumulators()[:, 1], 1)) / beta + g.get_offsets()
+    assert np.isfinite(en).all() and (en / nsite < 4.1 + 1e-9).all() and (en / nsite > -3.0).all()  # offset/N = 3 + 1 + 0.1
