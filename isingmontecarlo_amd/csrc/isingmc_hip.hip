@@ -30,6 +30,8 @@ struct isingmc_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     uint32_t last_launches = 0;
+    bool fast_diag = false;             // the diagonal-pass launch uses sse_fast.hip.h (headline geometry: LDS edge tables, 4 waves, N <= 4096)
+    size_t lds_bytes_fast = 0;
     bool fused_launch = false;          // ISINGMC_CFG_FUSED_LAUNCH: whole timesteps in one kernel (no diagonal-only launches)
     std::vector<hipEvent_t> evpool;     // per-launch events of the split path (bounded, see run())
     float pass_ms[2] = {0.f, 0.f};      // [0] diagonal-only launches, [1] all other launches of the last run
@@ -181,6 +183,12 @@ static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t 
     // edge table, per-wave rank tables (u16) and marker tables (u8); with the tables in HBM (tg) only the bit arrays remain
     if (tg) return (size_t)nwords * 2 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges;
     return (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
+}
+// dynamic LDS of the fast diagonal-pass launch (mirrors Lds<4>::carve up to o_cur, then FastLds: sse_fast.hip.h fast_carve)
+static size_t fast_lds_bytes(uint32_t N, uint32_t nwords, uint32_t E, uint32_t Nb) {
+    const size_t o_cur = (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * 4 + 16 + 2 * SSE_MAX_CHUNKS + E;
+    const size_t words = ((o_cur + 1) & ~(size_t)1) + 8 + Nb + N;
+    return (4 * words + 7) & ~(size_t)7;
 }
 static bool is_tg(const isingmc_batch *b) { return b->mode == SSE_MODE_GLOBAL_TABLES; }
 // dynamic LDS of the diagonal-pass launch: the fixed regions up to the per-wave tables, which it uses as [W][N] spin bytes
@@ -365,8 +373,9 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         LaunchCfg ld = lc;
         ld.W = b->W;
         ld.passes = SSE_PASSES_DIAG;
+        const bool use_fast = b->fast_diag && !(A.domask & SSE_DO_HEATBATH);
         // the diagonal launch needs the fixed regions up to the per-wave tables, which it uses as [W][N] bytes
-        ld.lds_bytes = diag_lds_bytes(b);
+        ld.lds_bytes = use_fast ? b->lds_bytes_fast : diag_lds_bytes(b);
         const uint32_t rest = A.domask & ~diag_bits;
         constexpr size_t MAX_TIMED = 256;
         const size_t want_ev = 3 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
@@ -382,7 +391,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             SweepArgs a1 = A;
             a1.domask = A.domask & diag_bits; a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
             if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done], b->stream));
-            hipError_t e = launch(ld, a1);
+            hipError_t e = use_fast ? launch_sweep_fast(ld, b->dev, a1) : launch(ld, a1);
             if (e != hipSuccess) return fail_launch(e);
             launches++; b->pass_launches[0]++;
             if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done + 1], b->stream));
@@ -615,6 +624,9 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         D.stride = (uint32_t)((need + tile - 1) / tile * tile);
     }
     b->lds_fixed_words_ = fixed; b->lds_total_words = total_words; b->uf_ids_limit = cfg->lds_uf_ids_limit;
+    b->lds_bytes_fast = fast_lds_bytes(D.N, D.nwords, D.E, D.Nb);
+    b->fast_diag = CL && !TG && W == 4 && (K == 4 || K == 2) && D.N <= SSE_FAST_MAX_VARS && !b->fused_launch &&
+                   !(cfg->flags & ISINGMC_CFG_NO_FAST_DIAG) && b->lds_bytes_fast <= 40 * 1024; // 4 workgroups per CU
     { // the RVB pass reuses everything from the scan tables on: launches that run it get enough LDS for its scratch
       // and constant-op table (other launches keep the smaller footprint, which decides workgroups per CU)
         const size_t o_cur = TG ? fixed : fixed - ((size_t)W * D.N + 1) / 2 - ((size_t)W * D.N + 3) / 4;
@@ -1048,7 +1060,7 @@ int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
+    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
     return ISINGMC_OK;
 }
 

@@ -113,7 +113,8 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
         // one v_mad_u64_u32 per 32x32->64 product (hi and lo halves together) instead of v_mul_hi + v_mul_lo
         const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        // three-input xor in one instruction (gfx950 v_bitop3_b32, truth table 0x96)
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         if (i < 9) { k0 = philox_bump(k0, 0x9E3779B9u); k1 = philox_bump(k1, 0xBB67AE85u); }
     }
@@ -1397,6 +1398,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
 
 } // namespace sse
 #include "sse_rvb.hip.h"
+#include "sse_fast.hip.h"
 namespace sse {
 
 // ---------------------------------------------------------------------------------------------
@@ -1527,6 +1529,7 @@ hipError_t launch_sweep_w4(const LaunchCfg &c, const DevBatch &B, const SweepArg
 hipError_t launch_sweep_w6(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_w8(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_w16(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
+hipError_t launch_sweep_fast(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A); // sweep_fast.hip: sse_fast.hip.h, W = 4
 
 template <int W, int K, int CL, int PHASE, int PASSES>
 hipError_t launch_one(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
