@@ -27,6 +27,13 @@ namespace sse {
 #define SSE_FAST_CLASS_G 1u
 #define SSE_FAST_CLASS_H 2u
 
+// v_cndmask on a wave mask held in scalar registers: mask bit of the lane set ? a : b
+__device__ __forceinline__ uint32_t sel64(uint64_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+
 struct FastLds {
     uint32_t o_nb;   // [4] f64: beta*Nb*weight per class
     uint32_t o_tab;  // [Nb] packed bond entries
@@ -105,40 +112,52 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         const bool partial = tile * TS + TS > M; // wave-uniform: only the last tile can hold slots >= M
 
         double ua[K], un[K], nb[K];
-        uint32_t cbv[K], neww[K];
-        uint64_t insm[K], remm[K], trm[K], acc[K];
-        uint4 rnd = make_uint4(0, 0, 0, 0);
+        uint32_t cbv[K], neww[K], ent[K], bnd[K], rr1[K];
+        uint64_t insm[K], remm[K], acc[K], occm[K], evm[K];
+        // Lane predicates are kept as explicit wave masks (one v_cmp each, combined on the scalar unit) and selects are
+        // written as v_cndmask on those masks: left to itself the compiler turns `c ? a : b` on lane booleans into
+        // exec-masked branches and re-materialises every combined predicate through a 0/1 register and a second compare.
+        // ---- phase 1, all rows at once (nothing here depends on the spin tables): random numbers, bond, packed table entry
+        {
+            uint4 rnd = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t wd = word[j];
+                occm[j] = sse_ballot(wd != 0u);
+                evm[j] = sse_ballot(((wd ^ (wd >> 2)) & 1u) != 0u);
+                if ((j & 1) == 0) rnd = rng.draw(SSE_TAG_DIAG, pbase + (uint32_t)(j * 64)); // bit 6 of the slot index is clear on even rows
+                const uint32_t r0 = (j & 1) ? rnd.z : rnd.x;
+                rr1[j] = (j & 1) ? rnd.w : rnd.y;
+                bnd[j] = sel64(occm[j], (wd >> 4) - 1u, __umulhi(r0, Nb));
+                ent[j] = LDSW(F.o_tab, bnd[j]);
+            }
+        }
+        // ---- phase 2, row after row: the propagated spins of the two variables.  In-row ordering of the off-diagonal ops: they
+        // publish (lane + 1, spin before) in their variable's byte, everybody reads, they store the spin after.  (Rows without
+        // such an op run the same code: no marker, no correction.)
+        uint32_t sub0[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const uint32_t p = pbase + (uint32_t)(j * 64);
-            const uint32_t wd = word[j];
-            const bool occ = wd != 0u;
-            const uint32_t inb = wd & 1u;
-            const bool isev = ((wd ^ (wd >> 2)) & 1u) != 0u;
-            const bool valid = partial ? (p < M) : true;
-            const bool is_empty = valid & !occ, is_diag = occ & !isev;
-            if ((j & 1) == 0) rnd = rng.draw(SSE_TAG_DIAG, p); // bit 6 of p is clear on even rows: p == p & ~64
-            const uint32_t r0 = (j & 1) ? rnd.z : rnd.x, r1 = (j & 1) ? rnd.w : rnd.y;
-            const uint32_t b = occ ? (wd >> 4) - 1u : __umulhi(r0, Nb);
-            const uint32_t e = LDSW(F.o_tab, b);
+            const uint32_t e = ent[j], inb = word[j] & 1u;
             const uint32_t va = e & 0xFFFu, vc = (e >> 12) & 0xFFFu;
             const uint32_t adr_a = spin_my + 4u * va, adr_c = spin_my + 4u * vc;
-            // in-row ordering of the off-diagonal ops: they publish (lane + 1, spin before) in their variable's byte, everybody
-            // reads, they store the spin after.  (Rows without such an op run the same code: no marker, no correction.)
-            if (isev) LDS8(adr_a) = (uint8_t)(lane1x2 | inb);
+            const uint32_t mark = lane1x2 | inb;
+            const bool isev = ((evm[j] >> lane) & 1ull) != 0ull;
+            if (isev) LDS8(adr_a) = (uint8_t)mark;
             SSE_WAVE_FENCE();
             const uint32_t ea = LDS8(adr_a), ec = LDS8(adr_c);
-            const uint32_t La = ea >> 1, Lc = ec >> 1;
-            uint32_t sa = ea & 1u, sc = ec & 1u;
-            const uint64_t dup = sse_ballot(isev & (ea != (lane1x2 | inb)));
+            uint32_t sa, sc;
+            const uint64_t dup = sse_ballot(ea != mark) & evm[j];
             if (!dup) {
-                sa ^= (uint32_t)((La - 1u) < (uint32_t)lane); // La == 0: no off-diagonal op on the variable in this row
-                sc ^= (uint32_t)((Lc - 1u) < (uint32_t)lane);
+                // flip = the marker's lane is below mine: (L - 1) <u lane, L = ea >> 1 (0 = no off-diagonal op on the variable)
+                sa = (ea ^ (uint32_t)(((ea >> 1) - 1u) < (uint32_t)lane)) & 1u;
+                sc = (ec ^ (uint32_t)(((ec >> 1) - 1u) < (uint32_t)lane)) & 1u;
                 SSE_WAVE_FENCE();
                 if (isev) LDS8(adr_a) = (uint8_t)(inb ^ 1u);
             } else { // two off-diagonal ops of this row on one variable (rare): resolve in lane order
+                sa = ea & 1u; sc = ec & 1u;
                 bool seen_a = false, seen_c = false;
-                uint64_t m = sse_ballot(isev);
+                uint64_t m = evm[j];
                 while (m) {
                     const int Ls = __ffsll((long long)m) - 1;
                     m &= m - 1;
@@ -150,21 +169,24 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
                 }
                 SSE_WAVE_FENCE();
             }
-            const uint32_t sub0 = sa | (sc << 1);
-            const bool ok = ((e >> (24u + sub0)) & 1u) != 0u;
-            const uint32_t sub = sub0 & ((e >> 28) & 3u);
-            const uint32_t cls = e >> 30;
-            const double nbj = *reinterpret_cast<const double *>(&lds_raw[F.o_nb + 2u * cls]);
-            const double u = u01(r1);
-            const bool ins = is_empty & ok;
-            insm[j] = sse_ballot(ins);
-            remm[j] = sse_ballot(is_diag);
-            trm[j] = sse_ballot(cls == SSE_FAST_CLASS_G);
+            sub0[j] = sa | (sc << 1);
+        }
+        // ---- phase 3, all rows: candidates and the operands of the rule
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t e = ent[j];
+            const uint64_t validm = partial ? sse_ballot(pbase + (uint32_t)(j * 64) < M) : ~0ull;
+            const uint64_t okm = sse_ballot(((e >> (24u + sub0[j])) & 1u) != 0u);
+            const uint32_t sub = sub0[j] & (e >> 28) & 3u;
+            const double nbj = *reinterpret_cast<const double *>(&lds_raw[F.o_nb + 2u * (e >> 30)]);
+            const double u = u01(rr1[j]);
+            insm[j] = validm & ~occm[j] & okm; // empty slot, and a diagonal op on the drawn bond has weight here
+            remm[j] = occm[j] & ~evm[j];       // diagonal op
             ua[j] = u;          // insert:  u * den < num
             un[j] = u * nbj;    // remove:  u * num < den
             nb[j] = nbj;
-            cbv[j] = M + (ins ? 0u : 1u);
-            neww[j] = ins ? (((b + 1u) << 4) | sub | (sub << 2)) : 0u; // what an accepted candidate leaves in the slot
+            cbv[j] = sel64(insm[j], M, M + 1u);
+            neww[j] = sel64(insm[j], ((bnd[j] + 1u) << 4) | sub | (sub << 2), 0u); // what an accepted candidate leaves in the slot
             acc[j] = 0ull;
         }
 
@@ -223,8 +245,9 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         for (int j = 0; j < K; ++j) {
             row_st(ops, pbase + (uint32_t)(j * 64), ((acc[j] >> lane) & 1ull) ? neww[j] : word[j]);
             const uint64_t im = acc[j] & insm[j], rm = acc[j] & remm[j];
+            const uint64_t trm = sse_ballot((ent[j] >> 30) == SSE_FAST_CLASS_G); // the bond at stake is a transverse-field bond
             dn += popc64(im) - popc64(rm);
-            dtr += popc64(im & trm[j]) - popc64(rm & trm[j]);
+            dtr += popc64(im & trm) - popc64(rm & trm);
         }
         ntrans += dtr;
         if (lane == 0 && (dtr | dn)) { // the 64*K slots of a wave's share of a tile lie inside one chunk
