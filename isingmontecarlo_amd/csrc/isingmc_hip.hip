@@ -187,7 +187,7 @@ static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t 
 // dynamic LDS of the fast diagonal-pass launch (mirrors Lds<4>::carve up to o_cur, then FastLds: sse_fast.hip.h fast_carve)
 static size_t fast_lds_bytes(uint32_t N, uint32_t nwords, uint32_t E, uint32_t Nb) {
     const size_t o_cur = (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * 4 + 16 + 2 * SSE_MAX_CHUNKS + E;
-    const size_t words = ((o_cur + 1) & ~(size_t)1) + 8 + Nb + N;
+    const size_t words = ((o_cur + 3) & ~(size_t)3) + 16 + Nb + N + 64;
     return (4 * words + 7) & ~(size_t)7;
 }
 static bool is_tg(const isingmc_batch *b) { return b->mode == SSE_MODE_GLOBAL_TABLES; }

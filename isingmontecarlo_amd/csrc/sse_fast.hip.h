@@ -34,19 +34,29 @@ __device__ __forceinline__ uint32_t sel64(uint64_t mask, uint32_t a, uint32_t b)
     return r;
 }
 
+// bitfield insert: (a & mask) | (b & ~mask)
+// (as an instruction: written in C the optimiser turns it back into compare + select, the very thing it is here to avoid)
+__device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+
 struct FastLds {
-    uint32_t o_nb;   // [4] f64: beta*Nb*weight per class
+    uint32_t o_nb;   // [4][2] f64 per class: beta*Nb*weight * 2^32 and beta*Nb*weight * 2^-32 (the 2^-32 of the uniform folded in)
     uint32_t o_tab;  // [Nb] packed bond entries
     uint32_t o_spin; // [N] u32: byte w = wave w's copy of the propagated spin (bit 0) + in-row event marker (bits 1..7)
+    uint32_t o_dummy; // [64] one word per lane: target of the stores / atomics of lanes that have nothing to store
     uint32_t end;
 };
 template <int W>
 __device__ __forceinline__ FastLds fast_carve(const Lds<W> &L, const DevBatch &B) {
     FastLds F;
-    uint32_t base = (L.o_cur + 1u) & ~1u; // even: doubles are 8-byte aligned
-    F.o_nb = base; base += 8;
+    uint32_t base = (L.o_cur + 3u) & ~3u; // 16-byte aligned: the class constants are read as one b128
+    F.o_nb = base; base += 16;
     F.o_tab = base; base += B.Nb;
     F.o_spin = base; base += B.N;
+    F.o_dummy = base; base += 64;
     F.end = base;
     return F;
 }
@@ -80,16 +90,21 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
     const uint32_t m_later = (uint32_t)((0x0101010100ull << (8 * wave)) & 0xFFFFFFFFull);
     const uint32_t m_earlier = 0x01010101u & ((1u << (8 * wave)) - 1u);
     const uint32_t spin_my = 4u * F.o_spin + (uint32_t)wave; // byte address of this wave's copy of variable 0
-    const uint32_t lane1x2 = ((uint32_t)lane + 1u) << 1;
+    const uint32_t markhi = (127u - (uint32_t)lane) << 1; // marker of an off-diagonal op of this lane (bits 1..7 of its variable's byte)
 
-    // flip the spin of the off-diagonal ops among K words in the copies selected by `mask` (CL: only transverse ops flip)
+    // Predicated LDS stores and atomics are written branch-free: lanes that have nothing to do are pointed at a per-lane dummy
+    // word instead (an address select costs two integer instructions; an exec-masked store costs a compare, a mask in two
+    // scalar registers and an exec save / restore).
+    const uint32_t dummy_w = F.o_dummy + (uint32_t)lane; // word index of this lane's dummy word
+    // all-ones iff the op word is off-diagonal (CL: only transverse-field ops can be: bit 0 of in ^ out)
+    auto evmask32 = [](uint32_t wd) -> uint32_t { return 0u - ((wd ^ (wd >> 2)) & 1u); };
+    // flip the spin of the off-diagonal ops among K words in the copies selected by `mask`
     auto propagate = [&](const uint32_t (&wd)[K], uint32_t mask) {
         if (mask == 0u) return; // wave-uniform
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const bool isev = ((wd[j] ^ (wd[j] >> 2)) & 1u) != 0u;
-            const uint32_t v = (wd[j] >> 4) - 1u - E;
-            if (isev) atomicXor(&LDSW(F.o_spin, v), mask);
+            const uint32_t v = F.o_spin + (wd[j] >> 4) - 1u - E;
+            atomicXor(&lds_raw[bfi32(evmask32(wd[j]), v, dummy_w)], mask);
         }
     };
 
@@ -98,6 +113,8 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
     for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, (uint32_t)(wave * 64 * K + j * 64 + lane));
     propagate(wnext, m_later);
     __syncthreads();
+    const uint32_t lane2 = 2u * (uint32_t)lane;
+    const uint32_t vM = vgpr_copy_u32(M), vM1 = vgpr_copy_u32(M + 1u), vzero = vgpr_copy_u32(0u);
 
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
         uint32_t word[K];
@@ -113,51 +130,50 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
 
         double ua[K], un[K], nb[K];
         uint32_t cbv[K], neww[K], ent[K], bnd[K], rr1[K];
-        uint64_t insm[K], remm[K], acc[K], occm[K], evm[K];
-        // Lane predicates are kept as explicit wave masks (one v_cmp each, combined on the scalar unit) and selects are
-        // written as v_cndmask on those masks: left to itself the compiler turns `c ? a : b` on lane booleans into
-        // exec-masked branches and re-materialises every combined predicate through a 0/1 register and a second compare.
+        uint64_t insm[K], remm[K], acc[K];
+        // Lane predicates that have to survive the rounds are wave masks (insert candidates, removal candidates, accepted);
+        // everything else is recomputed from the op word with integer arithmetic when needed — the pass is short of scalar
+        // registers, and a spilled mask costs a v_readlane per half and use.
         // ---- phase 1, all rows at once (nothing here depends on the spin tables): random numbers, bond, packed table entry
         {
             uint4 rnd = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const uint32_t wd = word[j];
-                occm[j] = sse_ballot(wd != 0u);
-                evm[j] = sse_ballot(((wd ^ (wd >> 2)) & 1u) != 0u);
                 if ((j & 1) == 0) rnd = rng.draw(SSE_TAG_DIAG, pbase + (uint32_t)(j * 64)); // bit 6 of the slot index is clear on even rows
                 const uint32_t r0 = (j & 1) ? rnd.z : rnd.x;
                 rr1[j] = (j & 1) ? rnd.w : rnd.y;
-                bnd[j] = sel64(occm[j], (wd >> 4) - 1u, __umulhi(r0, Nb));
+                bnd[j] = sel64(sse_ballot(wd != 0u), (wd >> 4) - 1u, __umulhi(r0, Nb));
                 ent[j] = LDSW(F.o_tab, bnd[j]);
             }
         }
         // ---- phase 2, row after row: the propagated spins of the two variables.  In-row ordering of the off-diagonal ops: they
-        // publish (lane + 1, spin before) in their variable's byte, everybody reads, they store the spin after.  (Rows without
-        // such an op run the same code: no marker, no correction.)
+        // publish (127 - lane, spin before) in their variable's byte, everybody reads, they store the spin after.  A reader's
+        // spin is flipped iff the publishing lane is below its own: 127 - L' < lane, i.e. bit 8 of (byte + 2 * lane) — plain
+        // integer arithmetic, no compare.  (Rows without such an op run the same code: clean bytes have L' = 0, never a flip.)
         uint32_t sub0[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const uint32_t e = ent[j], inb = word[j] & 1u;
             const uint32_t va = e & 0xFFFu, vc = (e >> 12) & 0xFFFu;
             const uint32_t adr_a = spin_my + 4u * va, adr_c = spin_my + 4u * vc;
-            const uint32_t mark = lane1x2 | inb;
-            const bool isev = ((evm[j] >> lane) & 1ull) != 0ull;
-            if (isev) LDS8(adr_a) = (uint8_t)mark;
+            const uint32_t mark = markhi | inb;
+            const uint32_t ev32 = evmask32(word[j]);
+            const uint32_t adr_w = bfi32(ev32, adr_a, 4u * dummy_w); // where this lane stores: its variable's byte, or its dummy
+            LDS8(adr_w) = (uint8_t)mark;
             SSE_WAVE_FENCE();
             const uint32_t ea = LDS8(adr_a), ec = LDS8(adr_c);
             uint32_t sa, sc;
-            const uint64_t dup = sse_ballot(ea != mark) & evm[j];
+            const uint64_t dup = sse_ballot(((ea ^ mark) & ev32) != 0u); // an off-diagonal op whose marker was overwritten
             if (!dup) {
-                // flip = the marker's lane is below mine: (L - 1) <u lane, L = ea >> 1 (0 = no off-diagonal op on the variable)
-                sa = (ea ^ (uint32_t)(((ea >> 1) - 1u) < (uint32_t)lane)) & 1u;
-                sc = (ec ^ (uint32_t)(((ec >> 1) - 1u) < (uint32_t)lane)) & 1u;
+                sa = (ea ^ ((ea + lane2) >> 8)) & 1u;
+                sc = (ec ^ ((ec + lane2) >> 8)) & 1u;
                 SSE_WAVE_FENCE();
-                if (isev) LDS8(adr_a) = (uint8_t)(inb ^ 1u);
+                LDS8(adr_w) = (uint8_t)(inb ^ 1u);
             } else { // two off-diagonal ops of this row on one variable (rare): resolve in lane order
                 sa = ea & 1u; sc = ec & 1u;
                 bool seen_a = false, seen_c = false;
-                uint64_t m = evm[j];
+                uint64_t m = sse_ballot(ev32 != 0u);
                 while (m) {
                     const int Ls = __ffsll((long long)m) - 1;
                     m &= m - 1;
@@ -174,19 +190,19 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         // ---- phase 3, all rows: candidates and the operands of the rule
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const uint32_t e = ent[j];
-            const uint64_t validm = partial ? sse_ballot(pbase + (uint32_t)(j * 64) < M) : ~0ull;
-            const uint64_t okm = sse_ballot(((e >> (24u + sub0[j])) & 1u) != 0u);
+            const uint32_t e = ent[j], wd = word[j];
+            const uint32_t okbit = (e >> (24u + sub0[j])) & 1u; // a diagonal op on this bond has weight in this spin state
             const uint32_t sub = sub0[j] & (e >> 28) & 3u;
-            const double nbj = *reinterpret_cast<const double *>(&lds_raw[F.o_nb + 2u * (e >> 30)]);
-            const double u = u01(rr1[j]);
-            insm[j] = validm & ~occm[j] & okm; // empty slot, and a diagonal op on the drawn bond has weight here
-            remm[j] = occm[j] & ~evm[j];       // diagonal op
-            ua[j] = u;          // insert:  u * den < num
-            un[j] = u * nbj;    // remove:  u * num < den
-            nb[j] = nbj;
-            cbv[j] = sel64(insm[j], M, M + 1u);
-            neww[j] = sel64(insm[j], ((bnd[j] + 1u) << 4) | sub | (sub << 2), 0u); // what an accepted candidate leaves in the slot
+            const double2 nbp = *reinterpret_cast<const double2 *>(&lds_raw[F.o_nb + 4u * (e >> 30)]);
+            const double u = (double)rr1[j]; // the uniform is u * 2^-32: the power of two sits in the two table constants (exact)
+            insm[j] = sse_ballot(okbit > wd); // empty slot (word 0) and okbit 1
+            if (partial) insm[j] &= sse_ballot(pbase + (uint32_t)(j * 64) < M);
+            remm[j] = sse_ballot((wd & ~evmask32(wd)) != 0u); // occupied and diagonal
+            ua[j] = u;          // insert:  (u 2^-32) * den < num   <=>  u * den < num * 2^32
+            un[j] = u * nbp.y;  // remove:  (u 2^-32) * num < den   with  u * (num 2^-32) == (u 2^-32) * num  bit for bit
+            nb[j] = nbp.x;
+            cbv[j] = sel64(insm[j], vM, vM1);
+            neww[j] = sel64(insm[j], ((bnd[j] + 1u) << 4) | sub | (sub << 2), vzero); // what an accepted candidate leaves in the slot
             acc[j] = 0ull;
         }
 
@@ -243,7 +259,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         int dn = 0, dtr = 0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            row_st(ops, pbase + (uint32_t)(j * 64), ((acc[j] >> lane) & 1ull) ? neww[j] : word[j]);
+            row_st(ops, pbase + (uint32_t)(j * 64), sel64(acc[j], neww[j], word[j]));
             const uint64_t im = acc[j] & insm[j], rm = acc[j] & remm[j];
             const uint64_t trm = sse_ballot((ent[j] >> 30) == SSE_FAST_CLASS_G); // the bond at stake is a transverse-field bond
             dn += popc64(im) - popc64(rm);
@@ -286,7 +302,9 @@ __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArg
     if (tid < 4) {
         const double beta_nb = beta * (double)B.Nb;
         const double w = tid == 0 ? B.wJ : (tid == 1 ? B.gamma : (tid == 2 ? B.wh : 0.0));
-        *reinterpret_cast<double *>(&lds_raw[F.o_nb + 2u * (uint32_t)tid]) = beta_nb * w;
+        const double num = beta_nb * w; // the general pass' nbond, then scaled by exact powers of two
+        *reinterpret_cast<double *>(&lds_raw[F.o_nb + 4u * (uint32_t)tid]) = num * 4294967296.0;
+        *reinterpret_cast<double *>(&lds_raw[F.o_nb + 4u * (uint32_t)tid + 2u]) = num * (1.0 / 4294967296.0);
     }
     __syncthreads();
     int n = (int)B.n[r], ntrans = (int)B.ntrans[r];
