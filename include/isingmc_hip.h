@@ -52,6 +52,9 @@ extern "C" {
                                         ISINGMC_CFG_NO_LDS_TABLES or non-uniform couplings; slots_per_lane 1 or 4; no RVB updates. */
 #define ISINGMC_CFG_NO_FAST_DIAG 16u /* run the diagonal pass through the general kernel even where the instruction-trimmed one
                                         (csrc/sse_fast.hip.h: uniform |J|, N <= 4096, 4 waves per replica) applies (testing / A-B timing) */
+#define ISINGMC_CFG_FAST_LABEL 32u /* experimental: the trimmed diagonal kernel also labels the worldline segments and hands them to the
+                                      cluster update of the same timestep, which then only runs the union-find (same results; on MI355X the
+                                      diagonal launch loses more than the cluster update gains, see DESIGN.md, so it is off by default) */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 
@@ -213,7 +216,8 @@ int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
 /* build/launch configuration actually in use: out[0]=waves per replica, out[1]=dynamic LDS bytes,
  * out[2]=union-find ids that fit in LDS, out[3]=state words per replica, out[4]=slots per lane,
  * out[5]=1 if the edge table is staged in LDS, out[6]=bit 0: timesteps are issued as two launches (diagonal, rest); bit 1: per-variable
- * tables live in HBM (ISINGMC_CFG_GLOBAL_TABLES path); bit 2: the diagonal-pass launch is the trimmed kernel of sse_fast.hip.h; bits 8-15: waves per replica of the
+ * tables live in HBM (ISINGMC_CFG_GLOBAL_TABLES path); bit 2: the diagonal-pass launch is the trimmed kernel of sse_fast.hip.h; bit 3: ... and it labels the segments for the cluster
+ * update of the same timestep; bits 8-15: waves per replica of the
  * most recent off-diagonal launch,
  * out[7]=dynamic LDS bytes of the diagonal-pass launch */
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]);

@@ -31,7 +31,8 @@ struct isingmc_batch {
     float last_ms = 0.f;
     uint32_t last_launches = 0;
     bool fast_diag = false;             // the diagonal-pass launch uses sse_fast.hip.h (headline geometry: LDS edge tables, 4 waves, N <= 4096)
-    size_t lds_bytes_fast = 0;
+    size_t lds_bytes_fast = 0, lds_bytes_fast_label = 0;
+    bool lite = false;                  // ... and it labels the segments for the cluster update that follows in the same timestep
     bool fused_launch = false;          // ISINGMC_CFG_FUSED_LAUNCH: whole timesteps in one kernel (no diagonal-only launches)
     std::vector<hipEvent_t> evpool;     // per-launch events of the split path (bounded, see run())
     float pass_ms[2] = {0.f, 0.f};      // [0] diagonal-only launches, [1] all other launches of the last run
@@ -185,9 +186,10 @@ static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t 
     return (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
 }
 // dynamic LDS of the fast diagonal-pass launch (mirrors Lds<4>::carve up to o_cur, then FastLds: sse_fast.hip.h fast_carve)
-static size_t fast_lds_bytes(uint32_t N, uint32_t nwords, uint32_t E, uint32_t Nb) {
-    const size_t o_cur = (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * 4 + 16 + 2 * SSE_MAX_CHUNKS + E;
-    const size_t words = ((o_cur + 3) & ~(size_t)3) + 16 + Nb + N + 64;
+static size_t fast_lds_bytes(uint32_t N, uint32_t nwords, uint32_t E, uint32_t Nb, bool label) {
+    const size_t o_edges = (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * 4 + 16 + 2 * SSE_MAX_CHUNKS;
+    size_t words = ((o_edges + 3) & ~(size_t)3) + 16 + Nb + N + 64 + (label ? 4 * (size_t)N + ((size_t)N + 3) / 4 : 0);
+    if (words < o_edges + E) words = o_edges + E; // the directed loop behind the pass stages the compact edge table there
     return (4 * words + 7) & ~(size_t)7;
 }
 static bool is_tg(const isingmc_batch *b) { return b->mode == SSE_MODE_GLOBAL_TABLES; }
@@ -374,8 +376,11 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         ld.W = b->W;
         ld.passes = SSE_PASSES_DIAG;
         const bool use_fast = b->fast_diag && !(A.domask & SSE_DO_HEATBATH);
+        // the cluster update of the same timestep takes the segment labelling from the diagonal launch (nothing but the
+        // directed loop may sit in between: it changes no op's position or bond)
+        const bool use_label = use_fast && b->lite && (A.domask & SSE_DO_CLUSTER) && !(A.domask & SSE_DO_RVB);
         // the diagonal launch needs the fixed regions up to the per-wave tables, which it uses as [W][N] bytes
-        ld.lds_bytes = use_fast ? b->lds_bytes_fast : diag_lds_bytes(b);
+        ld.lds_bytes = use_fast ? (use_label ? b->lds_bytes_fast_label : b->lds_bytes_fast) : diag_lds_bytes(b);
         const uint32_t rest = A.domask & ~diag_bits;
         constexpr size_t MAX_TIMED = 256;
         const size_t want_ev = 3 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
@@ -389,7 +394,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             }
             const bool timed = done < MAX_TIMED;
             SweepArgs a1 = A;
-            a1.domask = A.domask & diag_bits; a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
+            a1.domask = (A.domask & diag_bits) | (use_label ? SSE_DO_LABEL : 0u); a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
             if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done], b->stream));
             hipError_t e = use_fast ? launch_sweep_fast(ld, b->dev, a1) : launch(ld, a1);
             if (e != hipSuccess) return fail_launch(e);
@@ -624,9 +629,13 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         D.stride = (uint32_t)((need + tile - 1) / tile * tile);
     }
     b->lds_fixed_words_ = fixed; b->lds_total_words = total_words; b->uf_ids_limit = cfg->lds_uf_ids_limit;
-    b->lds_bytes_fast = fast_lds_bytes(D.N, D.nwords, D.E, D.Nb);
+    b->lds_bytes_fast = fast_lds_bytes(D.N, D.nwords, D.E, D.Nb, false);
     b->fast_diag = CL && !TG && W == 4 && (K == 4 || K == 2) && D.N <= SSE_FAST_MAX_VARS && !b->fused_launch &&
                    !(cfg->flags & ISINGMC_CFG_NO_FAST_DIAG) && b->lds_bytes_fast <= 40 * 1024; // 4 workgroups per CU
+    // ... and labels the segments for the cluster update of the same timestep (h = 0: no frozen segments to track)
+    b->lds_bytes_fast_label = fast_lds_bytes(D.N, D.nwords, D.E, D.Nb, true);
+    // (opt-in: measured on MI355X the labelling costs the diagonal launch more than it saves the cluster update)
+    b->lite = b->fast_diag && !has_long && (cfg->flags & ISINGMC_CFG_FAST_LABEL) && b->lds_bytes_fast_label <= 40 * 1024;
     { // the RVB pass reuses everything from the scan tables on: launches that run it get enough LDS for its scratch
       // and constant-op table (other launches keep the smaller footprint, which decides workgroups per CU)
         const size_t o_cur = TG ? fixed : fixed - ((size_t)W * D.N + 1) / 2 - ((size_t)W * D.N + 3) / 4;
@@ -701,6 +710,15 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     }
     const size_t ufstride = ids_max + 2 * ((ids_max + 31) / 32);
     if ((rc = dalloc(b, &D.uf_scratch, (size_t)D.R * ufstride, false))) return fail(rc);
+    if (b->lite) {
+        D.lite = 1u;
+        if ((rc = dalloc(b, &D.pairs, (size_t)D.R * D.stride, false))) return fail(rc);
+        if ((rc = dalloc(b, &D.pcount, (size_t)D.R * 4))) return fail(rc);
+        if ((rc = dalloc(b, &D.lastrank, (size_t)D.R * D.N))) return fail(rc);
+        if ((rc = dalloc(b, &D.touchbits, (size_t)D.R * D.nwords))) return fail(rc);
+        if ((rc = dalloc(b, &D.lite_epoch, D.R, false))) return fail(rc);
+        if (hipMemset(D.lite_epoch, 0xFF, sizeof(uint64_t) * D.R) != hipSuccess) { b->err = "hipMemset failed"; return fail(ISINGMC_ENODEVICE); }
+    }
     if (TG) {
         D.tbl_stride = (uint32_t)((((size_t)Wmax * D.N * 3 + D.N) + 15) & ~(size_t)15);
         if ((rc = dalloc(b, &D.tbl, (size_t)D.R * D.tbl_stride))) return fail(rc);
@@ -1060,7 +1078,7 @@ int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
+    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u) | (b->lite ? 8u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
     return ISINGMC_OK;
 }
 

@@ -57,6 +57,16 @@ struct DevBatch {
     uint32_t *chunks;     // [R][2*SSE_MAX_CHUNKS]: per chunk of CH slots: occupied count, transverse-op count
     uint32_t CH, nchunks; // chunk size (multiple of 256 slots) and number of chunks covering cap
     uint32_t *uf_scratch; // [R][W*N+cap (+bit arrays)] union-find fallback in HBM
+    // hand-over from the trimmed diagonal kernel (sse_fast.hip.h) to the cluster update that follows it in the same timestep:
+    // the segment labelling rides on the diagonal pass (segs above is written there), the cluster update only unions
+    uint32_t lite;        // 1 = the arrays below exist
+    uint32_t *pairs;      // [R][stride]: segment-id pairs (lo | hi << 16) of the two-site ops, appended per wave: wave q of the
+                          // diagonal launch owns [q*stride/4, (q+1)*stride/4)
+    uint32_t *pcount;     // [R][4] pairs appended by each wave
+    uint16_t *lastrank;   // [R][N] 1 + dense index of the last cut on each worldline (0 = none): the wrap-around joins
+    uint32_t *touchbits;  // [R][nwords] variables that carry an op
+    uint64_t *lite_epoch; // [R] the update counter at which segs / pairs describe the op-string (any other primitive in between
+                          // moves the counter on and the cluster update falls back to its own scan)
     uint8_t *tbl;         // [R][tbl_stride] per-variable tables in HBM/L2 for models whose tables exceed LDS (MODE 2, see Tab)
     uint32_t tbl_stride;  // bytes per replica: Wmax*N*2 (cut ranks / spin bytes) + Wmax*N (cut markers) + N (touched), rounded up to 16
     uint32_t seed_lo, seed_hi, replica_offset;
@@ -86,6 +96,7 @@ struct DevBatch {
 #define SSE_DO_GROW 16u
 #define SSE_DO_HEATBATH 32u
 #define SSE_DO_RVB 64u
+#define SSE_DO_LABEL 128u // trimmed diagonal launch only: label the segments for the cluster update of the same timestep
 
 struct SweepArgs {
     const double *beta; // [R]
@@ -1036,10 +1047,11 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
 
 // Cluster update.  Reference: ClusterUpdater::flip_each_cluster_rng (qmc_traits/cluster.rs:36-172) with the
 // longitudinal weight function of qmc_ising.rs:759-775.  Returns the number of clusters.
-template <int W, int K, bool CL, bool UF_GLOBAL, bool TG>
+template <int W, int K, bool CL, bool UF_GLOBAL, bool TG, bool LITE = false>
 __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double prob,
                                                  uint32_t M, int n, int ntrans, uint32_t &gr, uint32_t &err) {
     static_assert(UF_GLOBAL || !TG, "tables in HBM imply the HBM union-find");
+    static_assert(!LITE || (!UF_GLOBAL && !TG && CL), "the hand-over from the trimmed diagonal kernel uses the LDS union-find");
     constexpr int NT = W * 64;
     const Tab<TG> T = make_tab<TG, W>(B, L, r);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1057,6 +1069,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     if (tid == 0) { LDSW(L.o_misc, MISC_NCLUST) = 0u; LDSW(L.o_misc, MISC_ANYFROZEN) = 0u; }
     if (n == 0) { __syncthreads(); return 0u; } // cluster.rs:46-48
     SSE_STAMP_INIT;
+    if constexpr (!LITE)
     { // the scan stores 16-bit cut ranks per wave range: every range must hold fewer than 65535 cuts
         const uint32_t used = (M + B.CH - 1) / B.CH, q = (used + W - 1) / W;
         uint32_t bad = 0;
@@ -1068,7 +1081,32 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
         if (bad) { err = 8u; return 0u; }
     }
     const uint32_t C = (uint32_t)ntrans;            // one id per cut (transverse op)
-    const uint32_t S = N + C + (uint32_t)(W - 1) * N; // + artificial range-boundary placeholders
+    const uint32_t S = LITE ? N + C : N + C + (uint32_t)(W - 1) * N; // + artificial range-boundary placeholders
+    if constexpr (LITE) {
+        // The diagonal pass of this timestep has already labelled every leg (B.segs) and listed the segment pairs that the
+        // two-site ops join (B.pairs): what is left of the build is the union-find itself.  Ids: [0,N) initial segments,
+        // N + k the segment opened by the k-th cut — no range placeholders, the labelling was done in one p-ordered stream.
+        for (uint32_t i = tid; i < S; i += NT) uf.set(i, i);
+        for (uint32_t i = tid; i < nwords; i += NT) LDSW(L.o_touch, i) = B.touchbits[(size_t)r * nwords + i];
+        __syncthreads();
+        const uint32_t *pairs = B.pairs + (size_t)r * B.stride;
+        const uint32_t reg = B.stride / 4u;
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t cnt = B.pcount[(size_t)r * 4 + q];
+            const uint32_t *pq = pairs + (size_t)q * reg;
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 4 * NT) { // four independent loads in flight per thread
+                uint32_t pr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)(u * NT + tid); pr[u] = i < cnt ? pq[i] : 0u; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (pr[u]) uf_union(uf, pr[u] & 0xFFFFu, pr[u] >> 16); // (a pair never has two equal ids, so 0 = none)
+            }
+        }
+        // worldlines are cyclic in imaginary time (cluster.rs:223-242): the segment behind the last cut on v is the one v starts in
+        const uint16_t *lastrank = B.lastrank + (size_t)r * N;
+        for (uint32_t v = tid; v < N; v += NT) { const uint32_t lr = lastrank[v]; if (lr) uf_union(uf, N + lr - 1u, v); }
+        __syncthreads();
+    } else {
     for (uint32_t i = tid; i < N; i += NT) uf.set(i, i);
     for (uint32_t i = tid; i < (uint32_t)(W - 1) * N; i += NT) uf.set(N + C + i, N + C + i);
     if (B.has_long) for (uint32_t i = tid; i < (S + 31) / 32; i += NT) uf.bits_clear(i);
@@ -1097,6 +1135,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
         if (seg_end != nxt) uf_union(uf, seg_end, nxt);
     }
     __syncthreads();
+    } // !LITE
     SSE_STAMP(2);
     // ---- flatten: parent[i] := exact root (no union runs any more), frozen marks move to roots ----
     for (uint32_t i = tid; i < S; i += NT) {
@@ -1479,7 +1518,17 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         if (A.domask & SSE_DO_CLUSTER) {
             const Rng rng = make_rng(B, r, epoch);
             const uint32_t S_ids = (uint32_t)W * B.N + (uint32_t)ntrans;
-            if constexpr (TG) last_out = cluster_pass<W, K, CL, true, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+            bool lite_done = false;
+            if constexpr (CL && !TG) {
+                // the trimmed diagonal kernel labelled the string for exactly this update (same update counter, nothing in between)
+                const uint32_t S_lite = B.N + (uint32_t)ntrans;
+                if (B.lite && B.lite_epoch[r] == epoch && S_lite <= B.lds_ufcap && S_lite <= 65535u) {
+                    last_out = cluster_pass<W, K, CL, false, false, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+                    lite_done = true;
+                }
+            }
+            if (lite_done) {}
+            else if constexpr (TG) last_out = cluster_pass<W, K, CL, true, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             else if (S_ids <= B.lds_ufcap && S_ids <= 65535u) last_out = cluster_pass<W, K, CL, false, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             else last_out = cluster_pass<W, K, CL, true, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             epoch++;

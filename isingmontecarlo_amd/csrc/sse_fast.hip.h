@@ -47,16 +47,24 @@ struct FastLds {
     uint32_t o_tab;  // [Nb] packed bond entries
     uint32_t o_spin; // [N] u32: byte w = wave w's copy of the propagated spin (bit 0) + in-row event marker (bits 1..7)
     uint32_t o_dummy; // [64] one word per lane: target of the stores / atomics of lanes that have nothing to store
+    uint32_t o_rank;  // [4][N] u32 (labelling only): row w = wave w's copy of "1 + dense index of the latest cut on the worldline"
+                      // (bits 0..15, 0 = none yet) + in-row cut marker (bits 16..23).  Wave-major: a wave's random accesses
+                      // spread over all 32 banks (variable-major would put every access of a wave on 8 of them)
+    uint32_t o_tb;    // [N] u8 (labelling only): the variable carries an op
     uint32_t end;
 };
+// The tables start where the general layout keeps the compact edge table: the directed loop behind the diagonal pass is the
+// only user of that table in this kernel and stages it when the tables below are dead.
 template <int W>
-__device__ __forceinline__ FastLds fast_carve(const Lds<W> &L, const DevBatch &B) {
+__device__ __forceinline__ FastLds fast_carve(const Lds<W> &L, const DevBatch &B, bool label) {
     FastLds F;
-    uint32_t base = (L.o_cur + 3u) & ~3u; // 16-byte aligned: the class constants are read as one b128
+    uint32_t base = (L.o_edges + 3u) & ~3u; // 16-byte aligned: the class constants are read as one b128
     F.o_nb = base; base += 16;
     F.o_tab = base; base += B.Nb;
     F.o_spin = base; base += B.N;
     F.o_dummy = base; base += 64;
+    F.o_rank = base; base += label ? 4u * B.N : 0u;
+    F.o_tb = base; base += label ? (B.N + 3u) / 4u : 0u;
     F.end = base;
     return F;
 }
@@ -72,7 +80,12 @@ __device__ __forceinline__ uint32_t fast_entry(const DevBatch &B, uint32_t b, ui
     return v | (v << 12) | ((B.hpos ? 0x8u : 0x1u) << 24) | (1u << 28) | (SSE_FAST_CLASS_H << 30);
 }
 
-template <int K>
+// LABEL: also label every leg of the final string with its segment id for the cluster update that follows in the same
+// timestep (cluster.rs:193-271 expand_whole_cluster's bookkeeping; the ordered-scan formulation of cluster_scan): B.segs per
+// slot, the segment pairs joined by two-site ops (B.pairs), touched variables, last cut per worldline.  The labelling of
+// tile t runs one tile late, behind the second barrier of tile t + 1: by then every wave knows how many cuts the earlier
+// waves kept in tile t (dense cut numbering in p order), and has received their cuts in its copy of the rank table.
+template <int K, bool LABEL>
 __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L, const FastLds &F, uint32_t r, const Rng &rng, double beta,
                                               uint32_t M, int &n_io, int &ntrans_io, uint32_t &gr) {
     constexpr int W = 4, NT = W * 64;
@@ -82,6 +95,10 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t N = B.N, Nb = B.Nb, E = B.E;
     for (uint32_t i = tid; i < N; i += NT) LDSW(F.o_spin, i) = ((LDSW(L.o_state, i >> 5) >> (i & 31)) & 1u) * 0x01010101u;
+    if constexpr (LABEL) {
+        for (uint32_t i = tid; i < 4u * N; i += NT) LDSW(F.o_rank, i) = 0u;
+        for (uint32_t i = tid; i < (N + 3u) / 4u; i += NT) LDSW(F.o_tb, i) = 0u;
+    }
     __syncthreads();
 
     const uint32_t ntiles = (M + TS - 1) / TS;
@@ -116,6 +133,103 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
     const uint32_t lane2 = 2u * (uint32_t)lane;
     const uint32_t vM = vgpr_copy_u32(M), vM1 = vgpr_copy_u32(M + 1u), vzero = vgpr_copy_u32(0u);
 
+    // ---- labelling pipeline state (LABEL) ----
+    uint32_t entp[K];         // previous tile: table entry of each slot's bond, with the truth-table bits replaced by "the final slot holds an op" (bit 24)
+    uint32_t rk1[K];          // previous tile: 1 + dense index of this lane's cut (0 = not a cut)
+    uint32_t cut2[K];         // the tile before: the same | variable << 16 (still owed to the copies of the earlier waves)
+#pragma unroll
+    for (int j = 0; j < K; ++j) { entp[j] = 0u; rk1[j] = 0u; cut2[j] = 0u; }
+    uint32_t cntp = 0;        // cuts this wave kept in the previous tile
+    uint32_t kbase_prev = 0;  // dense index of this wave's first cut in the previous tile
+    uint32_t cuts_before = 0; // cuts in all tiles before the previous one
+    uint32_t pcount = 0;      // pairs appended by this wave
+    uint32_t *const segs_row = B.segs + (size_t)r * B.stride;
+    uint32_t *const pairs_w = B.pairs + (size_t)r * B.stride + (size_t)wave * (B.stride / 4u);
+    // dense index of the first cut of this wave in the previous tile, from the counts of all waves (read behind a barrier)
+    auto cut_ranks = [&](uint32_t kbase) {
+        kbase_prev = kbase;
+        uint32_t k0 = kbase;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint64_t cutm = sse_ballot((entp[j] & 0xC1000000u) == ((SSE_FAST_CLASS_G << 30) | (1u << 24))); // an op, on a transverse-field bond
+            const uint32_t kown = __builtin_amdgcn_mbcnt_hi((uint32_t)(cutm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cutm, k0 + 1u));
+            rk1[j] = sel64(cutm, kown, vzero);
+            k0 += (uint32_t)popc64(cutm);
+        }
+    };
+    // cuts -> the rank-table copies of the waves [wlo, whi): a max (ranks grow with p); only the cut lanes take part
+    auto push_ranks = [&](const uint32_t (&va)[K], const uint32_t (&rk)[K], int wlo, int whi) {
+        if (wlo >= whi) return; // wave-uniform
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (rk[j] != 0u)
+                for (int w2 = wlo; w2 < whi; ++w2) atomicMax(&LDSW(F.o_rank, (uint32_t)w2 * N + va[j]), rk[j]);
+    };
+    // label the previous tile (index tl): rows in order, this wave's copy of the rank table carries the state between them.
+    // Lane predicates are 32-bit all-ones / zero values here (selects are v_bfi, stores go to the lane's dummy word): the only
+    // wave masks are the two that feed prefix counts.
+    const uint32_t rank_my_b = 4u * (F.o_rank + (uint32_t)wave * N), dummy_b = 4u * dummy_w, tb_b = 4u * F.o_tb;
+    const uint32_t vone = vgpr_copy_u32(1u);
+    auto label_tile = [&](uint32_t tl) {
+        const uint32_t pb = tl * TS + (uint32_t)(wave * 64 * K + lane);
+        const uint32_t Nm1 = N - 1u;
+        uint32_t k0 = kbase_prev; // dense index of the first cut of the row being labelled
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t e = entp[j], rk = rk1[j];
+            const uint32_t va = e & 0xFFFu, vc = (e >> 12) & 0xFFFu;
+            const uint32_t ba = rank_my_b + 4u * va, bc = rank_my_b + 4u * vc; // byte addresses of this wave's entries
+            const uint64_t cutm = sse_ballot(rk != 0u);
+            const uint32_t cut32 = sel64(cutm, ~vzero, vzero);
+            const uint32_t ne32 = (uint32_t)((int32_t)(e << 7) >> 31); // bit 24 of the entry: the slot holds an op
+            const uint32_t two32 = ne32 & (uint32_t)((int32_t)(e << 2) >> 31); // bit 29 of the entry: a two-site bond
+            const uint32_t kown1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(cutm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cutm, 1u)); // 1 + cuts of this row at earlier lanes
+            // in-row ordering (as in cluster_scan): the cut lanes publish 1 + their rank inside the row, everybody reads once
+            LDS8(bfi32(cut32, ba + 2u, dummy_b)) = (uint8_t)kown1;
+            SSE_WAVE_FENCE();
+            const uint32_t ea = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds_raw) + ba);
+            const uint32_t ec = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds_raw) + bc);
+            const uint32_t xa = ea & 0xFFFFu, xc = ec & 0xFFFFu, ma = (ea >> 16) & 0xFFu, mc = (ec >> 16) & 0xFFu;
+            uint32_t seg_a = xa ? Nm1 + xa : va, seg_c = xc ? Nm1 + xc : vc;
+            const uint64_t dup = cutm & sse_ballot(ma != kown1);
+            const uint32_t firstid = N + k0; // id of the row's first cut (wave-uniform)
+            if (!dup) {
+                seg_a = ((ma - 1u) < kown1 - 1u) ? firstid + (ma - 1u) : seg_a; // ma == 0: no cut on the variable in this row
+                seg_c = ((mc - 1u) < kown1 - 1u) ? firstid + (mc - 1u) : seg_c;
+                SSE_WAVE_FENCE();
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(lds_raw) + bfi32(cut32, ba, dummy_b)) = rk; // latest cut on the variable; clears the marker byte
+            } else { // two cuts of this row on one variable (rare): lane order decides
+                bool lastcut = (rk != 0u);
+                uint64_t m = cutm;
+                uint32_t idL = firstid;
+                while (m) {
+                    const int Ls = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const uint32_t vL = __builtin_amdgcn_readlane(va, Ls);
+                    const bool later = lane > Ls, same_a = va == vL;
+                    seg_a = (later & same_a) ? idL : seg_a;
+                    seg_c = (later & (vc == vL)) ? idL : seg_c;
+                    lastcut = lastcut & !((lane < Ls) & same_a);
+                    idL++;
+                }
+                SSE_WAVE_FENCE();
+                if (rk != 0u) LDS8(ba + 2u) = (uint8_t)0;
+                if (lastcut) *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(lds_raw) + ba) = rk; // the last cut wins
+                SSE_WAVE_FENCE();
+            }
+            LDS8(bfi32(ne32, tb_b + va, dummy_b)) = (uint8_t)vone;
+            LDS8(bfi32(ne32, tb_b + vc, dummy_b)) = (uint8_t)vone;
+            const uint32_t hi = bfi32(cut32, Nm1 + rk, bfi32(two32, seg_c, seg_a)); // cut: the segment it opens; two-site: the second leg's
+            row_st(segs_row, pb + (uint32_t)(j * 64), seg_a | (hi << 16));
+            const uint64_t twom = sse_ballot(two32 != 0u);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(twom >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)twom, pcount));
+            if (two32) row_st(pairs_w, pos, seg_a | (seg_c << 16));
+            pcount += (uint32_t)popc64(twom);
+            cut2[j] = rk | ((va & cut32) << 16);
+            k0 += (uint32_t)popc64(cutm);
+        }
+    };
+
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
         uint32_t word[K];
 #pragma unroll
@@ -128,7 +242,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         }
         const bool partial = tile * TS + TS > M; // wave-uniform: only the last tile can hold slots >= M
 
-        double ua[K], un[K], nb[K];
+        double un[K], nb[K];
         uint32_t cbv[K], neww[K], ent[K], bnd[K], rr1[K];
         uint64_t insm[K], remm[K], acc[K];
         // Lane predicates that have to survive the rounds are wave masks (insert candidates, removal candidates, accepted);
@@ -198,7 +312,8 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
             insm[j] = sse_ballot(okbit > wd); // empty slot (word 0) and okbit 1
             if (partial) insm[j] &= sse_ballot(pbase + (uint32_t)(j * 64) < M);
             remm[j] = sse_ballot((wd & ~evmask32(wd)) != 0u); // occupied and diagonal
-            ua[j] = u;          // insert:  (u 2^-32) * den < num   <=>  u * den < num * 2^32
+            // insert:  (u 2^-32) * den < num   <=>  u * den < num * 2^32  (u is converted again in every round: one instruction
+            // against two registers per row held across the rounds)
             un[j] = u * nbp.y;  // remove:  (u 2^-32) * num < den   with  u * (num 2^-32) == (u 2^-32) * num  bit for bit
             nb[j] = nbp.x;
             cbv[j] = sel64(insm[j], vM, vM1);
@@ -218,7 +333,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const double t = (double)(int)(cbv[j] - (uint32_t)npref[j]);
-                const uint64_t lt_ins = sse_ballot(ua[j] * t < nb[j]);
+                const uint64_t lt_ins = sse_ballot((double)rr1[j] * t < nb[j]);
                 const uint64_t lt_rem = sse_ballot(un[j] < t);
                 const uint64_t a = (lt_ins & insm[j]) | (lt_rem & remm[j]);
                 changed |= a != acc[j];
@@ -226,7 +341,8 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
                 wtot += popc64(a & insm[j]) - popc64(a & remm[j]);
             }
             const int buf = gr & 1;
-            if (lane == 0) { LDSI(L.o_tot, buf * W + wave) = wtot; LDSW(L.o_chg, buf * W + wave) = changed ? 1u : 0u; }
+            // (LABEL: the first round also carries the number of cuts this wave kept in the previous tile, above bit 0)
+            if (lane == 0) { LDSI(L.o_tot, buf * W + wave) = wtot; LDSW(L.o_chg, buf * W + wave) = (changed ? 1u : 0u) | (LABEL && first ? cntp << 1 : 0u); }
             __syncthreads();
             if (first) {
                 // this tile's off-diagonal ops -> copies of the earlier waves (every reader of this tile is done); the next
@@ -234,13 +350,32 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
                 propagate(word, m_earlier);
                 if (tile + 1 < ntiles) propagate(wnext, m_later);
             }
-            int base = 0; tot_all = 0; uint32_t anychg = 0;
+            int base = 0; tot_all = 0; uint32_t anychg = 0, cbase = 0, call = 0;
 #pragma unroll
             for (int w2 = 0; w2 < W; ++w2) {
                 const int t = __builtin_amdgcn_readfirstlane(LDSI(L.o_tot, buf * W + w2));
                 if (w2 < wave) base += t;
                 tot_all += t;
-                anychg |= (uint32_t)__builtin_amdgcn_readfirstlane((int)LDSW(L.o_chg, buf * W + w2));
+                const uint32_t cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)LDSW(L.o_chg, buf * W + w2));
+                anychg |= cw & 1u;
+                if (w2 < wave) cbase += cw >> 1;
+                call += cw >> 1;
+            }
+            if constexpr (LABEL) if (first) {
+                // the previous tile's cuts get their dense numbers and go to the copies of the later waves (read behind the next
+                // barrier); the cuts of the tile before that go to the copies of the earlier waves (which are done labelling it)
+                if (tile >= 1u) {
+                    cut_ranks(cuts_before + cbase);
+                    cuts_before += call;
+                    uint32_t va[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) va[j] = entp[j] & 0xFFFu;
+                    push_ranks(va, rk1, wave + 1, W);
+                }
+                uint32_t va2[K], rk2[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) { va2[j] = cut2[j] >> 16; rk2[j] = cut2[j] & 0xFFFFu; }
+                push_ranks(va2, rk2, 0, wave);
             }
             gr++;
             if (!first && !anychg) break;
@@ -257,13 +392,27 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         }
         // ---- commit ----
         int dn = 0, dtr = 0;
+        uint32_t fwn[K], cntn = 0u;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            row_st(ops, pbase + (uint32_t)(j * 64), sel64(acc[j], neww[j], word[j]));
+            const uint32_t fw = sel64(acc[j], neww[j], word[j]);
+            row_st(ops, pbase + (uint32_t)(j * 64), fw);
             const uint64_t im = acc[j] & insm[j], rm = acc[j] & remm[j];
             const uint64_t trm = sse_ballot((ent[j] >> 30) == SSE_FAST_CLASS_G); // the bond at stake is a transverse-field bond
             dn += popc64(im) - popc64(rm);
             dtr += popc64(im & trm) - popc64(rm & trm);
+            if constexpr (LABEL) {
+                fwn[j] = fw;
+                // cuts in the final string: transverse-field ops, diagonal or not = (kept ops | accepted inserts) on such bonds
+                cntn += (uint32_t)popc64(((sse_ballot(word[j] != 0u) & ~rm) | im) & trm);
+            }
+        }
+        if constexpr (LABEL) {
+            // label the previous tile now: behind the last barrier of this tile's rounds, and with the round state dead
+            if (tile >= 1u) label_tile(tile - 1u);
+#pragma unroll
+            for (int j = 0; j < K; ++j) entp[j] = (ent[j] & 0xF0FFFFFFu) | (min(fwn[j], 1u) << 24);
+            cntp = cntn;
         }
         ntrans += dtr;
         if (lane == 0 && (dtr | dn)) { // the 64*K slots of a wave's share of a tile lie inside one chunk
@@ -272,6 +421,44 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
             if (dtr) atomicAdd(&LDSW(L.o_chtr, ch), (uint32_t)dtr);
         }
         n_start += tot_all;
+    }
+    if constexpr (LABEL) if (ntiles > 0u) {
+        // drain the labelling pipeline: counts of the last tile, its cuts to the later waves, the owed ones to the earlier waves
+        const int buf = gr & 1;
+        if (lane == 0) LDSW(L.o_chg, buf * W + wave) = cntp << 1;
+        __syncthreads();
+        uint32_t cbase = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < W; ++w2) {
+            const uint32_t cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)LDSW(L.o_chg, buf * W + w2));
+            if (w2 < wave) cbase += cw >> 1;
+        }
+        gr++;
+        cut_ranks(cuts_before + cbase);
+        uint32_t va[K], va2[K], rk2[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { va[j] = entp[j] & 0xFFFu; va2[j] = cut2[j] >> 16; rk2[j] = cut2[j] & 0xFFFFu; }
+        push_ranks(va, rk1, wave + 1, W);
+        push_ranks(va2, rk2, 0, wave);
+        __syncthreads();
+        label_tile(ntiles - 1u);
+        __syncthreads();
+        // hand-over to the cluster update: last cut per worldline (all copies together have seen every cut), touched variables
+        uint16_t *lastrank = B.lastrank + (size_t)r * N;
+        for (uint32_t v = tid; v < N; v += NT) {
+            const uint32_t a = LDSW(F.o_rank, v) & 0xFFFFu, b2 = LDSW(F.o_rank, N + v) & 0xFFFFu;
+            const uint32_t c2 = LDSW(F.o_rank, 2u * N + v) & 0xFFFFu, d2 = LDSW(F.o_rank, 3u * N + v) & 0xFFFFu;
+            lastrank[v] = (uint16_t)max(max(a, b2), max(c2, d2));
+        }
+        for (uint32_t i = tid; i < B.nwords; i += NT) {
+            uint32_t bits = 0;
+            for (uint32_t k = 0; k < 8 && (i * 8 + k) < (N + 3) / 4; ++k) {
+                const uint32_t w = LDSW(F.o_tb, i * 8 + k);
+                bits |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * k);
+            }
+            B.touchbits[(size_t)r * B.nwords + i] = bits;
+        }
+        if (lane == 0) B.pcount[(size_t)r * 4 + wave] = pcount;
     }
     __syncthreads();
     if (lane == 0) LDSI(L.o_tot, wave) = ntrans;
@@ -286,17 +473,16 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
 
 // One launch = the diagonal sweep (and, if asked for, the directed loop behind it) of every replica: the first of the two
 // launches of a timestep (isingmc_hip.hip run()), for the geometry above.  PHASE only tags the symbol (see sweep_kernel).
-template <int K, int PHASE>
+template <int K, int PHASE, bool LABEL>
 __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArgs A) {
     constexpr int W = 4, NT = W * 64;
     Lds<W> L;
     L.carve(B.N, B.nwords, B.lds_ufcap, B.E, B.has_long);
-    const FastLds F = fast_carve<W>(L, B);
+    const FastLds F = fast_carve<W>(L, B, LABEL);
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
     const double beta = A.beta ? A.beta[r] : 0.0;
     for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_state, i) = B.state[(size_t)r * B.nwords + i];
-    for (uint32_t i = tid; i < B.E; i += NT) LDSW(L.o_edges, i) = B.edges_compact[i]; // the directed loop decodes through this table
     for (uint32_t i = tid; i < B.Nb; i += NT) LDSW(F.o_tab, i) = fast_entry(B, i, i < B.E ? B.edges_compact[i] : 0u);
     for (uint32_t i = tid; i < 2 * SSE_MAX_CHUNKS; i += NT) LDSW(L.o_chn, i) = B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i];
     if (tid < 4) {
@@ -315,7 +501,7 @@ __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArg
         if (err) break;
         if (A.domask & SSE_DO_DIAG) {
             const Rng rng = make_rng(B, r, epoch);
-            diagonal_fast<K>(B, L, F, r, rng, beta, M, n, ntrans, gr);
+            diagonal_fast<K, LABEL>(B, L, F, r, rng, beta, M, n, ntrans, gr);
             epoch++;
             a5 += M;
             if (A.domask & SSE_DO_GROW) { // qmc_ising.rs:786, qmc_runner.rs:197
@@ -324,6 +510,10 @@ __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArg
             }
         }
         if (A.domask & SSE_DO_LOOP) {
+            // the directed loop decodes through the compact edge table, which shares its LDS with the (now dead) diagonal tables
+            __syncthreads();
+            for (uint32_t i = tid; i < B.E; i += NT) LDSW(L.o_edges, i) = B.edges_compact[i];
+            __syncthreads();
             const Rng rng = make_rng(B, r, epoch);
             last_out = loop_pass<W, true>(B, L, r, rng, M, n, gr, err);
             epoch++;
@@ -339,6 +529,8 @@ __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArg
         if (A.out_u32) A.out_u32[r] = last_out;
         uint64_t *acc = B.acc + (size_t)B.acc_row[r] * 8;
         acc[4] += a4; acc[5] += a5;
+        // the labelling describes the string as the very next update finds it (cluster ids must fit 16 bits)
+        if constexpr (LABEL) B.lite_epoch[r] = (!err && A.nsteps == 1 && B.N + (uint32_t)ntrans <= 65535u) ? epoch : ~0ull;
     }
 }
 

@@ -598,3 +598,36 @@ def test_cubic_32_full_size_runs_on_the_global_tables_path(oracle):
     assert (n > 5 * nsite).all() and (n < 40 * nsite).all()       # still growing towards beta * (offset - E0) ~ 4 * 6 per site
     en = -(g.accumulators()[:, 0] / np.maximum(g.accumulators()[:, 1], 1)) / beta + g.get_offsets()
     assert np.isfinite(en).all() and (en / nsite < 4.1 + 1e-9).all() and (en / nsite > -3.0).all()  # offset/N = 3 + 1 + 0.1
+
+
+@pytest.mark.parametrize("k,flags", [(0, 0), (0, 1), (2, 0), (4, 1)])
+def test_segment_labelling_on_the_diagonal_kernel(oracle, k, flags):
+    """ISINGMC_CFG_FAST_LABEL (experimental): the trimmed diagonal kernel labels the worldline segments one tile late and
+    the cluster update of the same timestep only runs the union-find over the handed-over segment pairs.  Same Markov
+    chain as every other path: bit-exact against the oracle, with and without a directed loop in between, and when a
+    primitive is called out of band (the hand-over must then be ignored, not used stale)."""
+    import isingmontecarlo_amd as im
+    edges = lat.two_d_ferro(16)
+    R, beta = 12, 4.0
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 256, 1 << 15, 4711, R, waves=4 if k else 0, k=k, cfg_flags=im.CFG_FAST_LABEL)
+    info = g.launch_info()
+    assert info["fast_diagonal"] and info["fast_label"]
+    g.run(25, beta, sampling_freq=2, flags=flags)
+    oracle.batch_timesteps(reps, 25, [beta] * R, 2, flags)
+    assert_same(g, reps, "label hand-over")
+    g.single_diagonal_step(beta)   # out of band: labels nothing that a later cluster update may use
+    nc = g.single_cluster_step(flip_free=True)
+    for r, rep in enumerate(reps):
+        rep.diagonal_update(beta)
+        want = rep.n + rep.n // 2
+        if want > rep.cutoff:
+            assert rep.set_cutoff(want) == 0
+        assert nc[r] == rep.cluster_update(0.5)
+        rep.flip_free_spins()
+    g.run(6, beta, flags=flags)
+    oracle.batch_timesteps(reps, 6, [beta] * R, 1, flags)
+    assert_same(g, reps, "label hand-over after out-of-band primitives")
+    acc = g.accumulators()
+    for r, rep in enumerate(reps):
+        assert np.array_equal(acc[r, :7], rep.accumulators()[:7])
+    assert g.verify().all()
