@@ -18,6 +18,7 @@
 #ifndef ISINGMC_HIP_H
 #define ISINGMC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 #include "sse_format.h"
 
@@ -201,6 +202,42 @@ int isingmc_set_cutoffs(isingmc_batch *b, const uint32_t *cutoffs);
 /* replica r accumulates into row rows[r] of an accumulator table with nrows rows (default: nrows = R, rows[r] = r);
  * isingmc_get_accumulators then returns [nrows][8].  Used to keep statistics per temperature slot. */
 int isingmc_set_accumulator_rows(isingmc_batch *b, uint32_t nrows, const uint32_t *rows);
+
+/* ---- native tempering step: temperature blocks sharded over ranks, neighbour exchange point to point --------------------
+ * Rank g of `world` owns ntemps/world consecutive temperatures of every chain; its batch holds ntemps/world * nchains
+ * replicas (replica r starts as slot (g*tper + r / nchains, r % nchains), isingmc_config.replica_offset = g * R).  Swaps inside
+ * the block exchange temperature labels; at a block boundary the two ranks exchange the boundary walkers' operator counts
+ * (tempering_container.rs:274-302: the swap test needs nothing else) and, when a swap is accepted, the two configurations
+ * themselves, so that a rank always holds the configurations of its own temperatures.  Transport: RCCL ncclSend / ncclRecv on
+ * device buffers inside one group call per exchange once isingmc_pt_attach_nccl succeeded, otherwise the host-staged
+ * `transport` of the layout (one rank: none needed). */
+typedef struct isingmc_pt_transport {
+    void *ctx;
+    /* blocking exchange with rank `peer`: send sbytes from sbuf and receive rbytes into rbuf (host memory); 0 on success */
+    int (*sendrecv)(void *ctx, int peer, const void *sbuf, size_t sbytes, void *rbuf, size_t rbytes);
+    /* element-wise maximum over all ranks, in place; 0 on success */
+    int (*allreduce_max_u32)(void *ctx, uint32_t *buf, size_t count);
+} isingmc_pt_transport;
+typedef struct isingmc_pt_layout {
+    uint32_t struct_size;     /* = sizeof(isingmc_pt_layout) */
+    uint32_t ntemps, nchains; /* global */
+    uint32_t rank, world;
+    const double *betas;      /* [ntemps] */
+    uint64_t seed;            /* Philox key of the swap decisions (the same on every rank) */
+    const isingmc_pt_transport *transport; /* may be NULL when world == 1 */
+} isingmc_pt_layout;
+typedef struct isingmc_nccl_id { char internal[128]; } isingmc_nccl_id; /* = ncclUniqueId */
+/* TemperingContainer::new + add_qmc_stepper (tempering_container.rs:40-75) for a batch that already holds the replicas.
+ * With ISINGMC_CFG_PER_REPLICA_J the couplings belong to the temperature slot (row r of J = slot r of this rank) and swaps
+ * use GraphWeights::relative_weight (tempering_traits.rs:126-155; the fields are common to the batch). */
+int isingmc_pt_create(isingmc_batch *b, const isingmc_pt_layout *layout);
+/* ncclGetUniqueId (rank 0, then broadcast by the launcher) and ncclCommInitRank for this batch's rank / world */
+int isingmc_pt_nccl_unique_id(isingmc_nccl_id *out);
+int isingmc_pt_attach_nccl(isingmc_batch *b, const isingmc_nccl_id *id);
+/* TemperingContainer::tempering_step (tempering_container.rs:121-149).  *nswaps += swaps whose LOWER temperature this rank owns. */
+int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps);
+/* current labels of the local replicas: global slot (t * nchains + chain), its beta, and the configuration's identity */
+int isingmc_pt_get_slots(isingmc_batch *b, uint32_t *slot_of_replica, double *beta_of_replica, uint32_t *config_id_of_replica);
 
 /* stream plumbing: use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
 int isingmc_set_stream(isingmc_batch *b, void *hip_stream);

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-__all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
+__all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "NativeTemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
            "interaction_at", "interaction_sym_under_ising",
            "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J", "CFG_GLOBAL_TABLES", "CFG_NO_FAST_DIAG", "CFG_FAST_LABEL"]
 
@@ -51,6 +51,25 @@ class _Config(C.Structure):
                 ("interactions", C.c_void_p), ("ninteractions", C.c_uint32), ("energy_offset", C.c_double)]
 
 
+_PT_SENDRECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+_PT_ALLMAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t)
+
+
+class _PtTransport(C.Structure):
+    """include/isingmc_hip.h: isingmc_pt_transport"""
+    _fields_ = [("ctx", C.c_void_p), ("sendrecv", _PT_SENDRECV), ("allreduce_max_u32", _PT_ALLMAX)]
+
+
+class _PtLayout(C.Structure):
+    """include/isingmc_hip.h: isingmc_pt_layout"""
+    _fields_ = [("struct_size", C.c_uint32), ("ntemps", C.c_uint32), ("nchains", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32),
+                ("betas", C.POINTER(C.c_double)), ("seed", C.c_uint64), ("transport", C.POINTER(_PtTransport))]
+
+
+class _NcclId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
 # every symbol include/isingmc_hip.h declares: name -> (restype, argtypes)
 _vp, _u32, _u64, _f64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_double
 _P = C.POINTER
@@ -84,6 +103,11 @@ SYMBOLS = {
     "isingmc_verify": (C.c_int, [_vp, _P(C.c_uint8)]),
     "isingmc_pt_decide": (C.c_int, [_u64, _u64, _u32, _u32, _P(_f64), _P(_u32), _P(_u32), _P(_u64)]),
     "isingmc_set_cutoffs": (C.c_int, [_vp, _P(_u32)]),
+    "isingmc_pt_create": (C.c_int, [_vp, _P(_PtLayout)]),
+    "isingmc_pt_nccl_unique_id": (C.c_int, [_P(_NcclId)]),
+    "isingmc_pt_attach_nccl": (C.c_int, [_vp, _P(_NcclId)]),
+    "isingmc_pt_step": (C.c_int, [_vp, _P(_u64)]),
+    "isingmc_pt_get_slots": (C.c_int, [_vp, _P(_u32), _P(_f64), _P(_u32)]),
     "isingmc_set_accumulator_rows": (C.c_int, [_vp, _u32, _P(_u32)]),
     "isingmc_set_stream": (C.c_int, [_vp, _vp]),
     "isingmc_set_steps_per_launch": (C.c_int, [_vp, _u64]),
@@ -618,4 +642,4 @@ class Qmc(QmcIsingGraph):
         return self
 
 
-from .tempering import TemperingContainer, pt_decide  # noqa: E402
+from .tempering import TemperingContainer, NativeTemperingContainer, pt_decide  # noqa: E402

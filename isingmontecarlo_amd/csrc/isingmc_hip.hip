@@ -50,6 +50,8 @@ struct isingmc_batch {
     uint8_t *d_ok = nullptr;
     std::vector<void *> allocs;
     mutable std::string err;
+    struct PtState *pt = nullptr;       // native parallel tempering (isingmc_pt_*), see the end of this file
+    std::vector<uint32_t> ham_row_host; // [R] bond-table row of each local replica (tempering between different Hamiltonians), empty = identity
 };
 
 #define HIP_TRY(b, expr)                                                                              \
@@ -111,7 +113,7 @@ __global__ void verify_kernel(DevBatch B, uint32_t *scratch_state /*[R][nwords]*
         count++;
         const uint32_t b = sse_op_bond(w);
         if (b >= B.Nb) { good = false; break; }
-        const BondRec rec = B.bonds[(size_t)r * B.bond_stride + b];
+        const BondRec rec = B.bonds[(size_t)(B.ham_row ? B.ham_row[r] : r) * B.bond_stride + b];
         Bd d;
         d.a = rec.a_info & SSE_VAR_MASK; d.c = rec.c; d.kp = rec.a_info >> SSE_INFO_SHIFT; d.w = rec.w;
         const uint32_t in = sse_op_in(w), out = sse_op_out(w);
@@ -750,9 +752,11 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     return ISINGMC_OK;
 }
 
+static void pt_free(isingmc_batch *b);
 void isingmc_destroy(isingmc_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
+    pt_free(b);
     for (void *p : b->allocs) (void)hipFree(p);
     for (hipEvent_t ev : b->evpool) (void)hipEventDestroy(ev);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -901,7 +905,7 @@ int isingmc_pt_decide(uint64_t seed, uint64_t step, uint32_t nchains, uint32_t n
 double isingmc_get_offset(const isingmc_batch *b) { return b ? b->offset : 0.0; }
 int isingmc_get_offsets(const isingmc_batch *b, double *out) {
     if (!b || !out) return ISINGMC_EINVAL;
-    for (uint32_t r = 0; r < b->dev.R; ++r) out[r] = b->per_replica_J ? b->offsets[r] : b->offset;
+    for (uint32_t r = 0; r < b->dev.R; ++r) out[r] = b->per_replica_J ? b->offsets[b->ham_row_host.empty() ? r : b->ham_row_host[r]] : b->offset;
     return ISINGMC_OK;
 }
 uint32_t isingmc_num_bonds(const isingmc_batch *b) { return b ? b->dev.Nb : 0u; }
@@ -968,7 +972,7 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
     if (!b || (!words && nwords) || r >= b->dev.R) { if (b) b->err = "bad arguments to import_ops"; return ISINGMC_EINVAL; }
     if (nwords > b->dev.cap) { b->err = "op-string longer than capacity"; return ISINGMC_ECAPACITY; }
     uint32_t n = 0, ntr = 0;
-    const size_t hoff = b->per_replica_J ? (size_t)r * b->dev.Nb : 0; // this replica's bond table
+    const size_t hoff = b->per_replica_J ? (size_t)(b->ham_row_host.empty() ? r : b->ham_row_host[r]) * b->dev.Nb : 0; // this replica's bond table
     std::vector<uint32_t> chunks(2 * SSE_MAX_CHUNKS, 0u);
     for (uint32_t p = 0; p < nwords; ++p) {
         if (!words[p]) continue;
@@ -1079,6 +1083,393 @@ int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
     out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u) | (b->lite ? 8u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
+    return ISINGMC_OK;
+}
+
+} // extern "C"
+
+// =====================================================================================================================
+// Native parallel tempering (reference: TemperingContainer::tempering_step, parallel_tempering/tempering_container.rs:121-149,
+// perform_swaps / swap_on_chunks :241-302, GraphWeights::relative_weight tempering_traits.rs:126-155).
+//
+// Sharding: rank g of G owns a contiguous block of ntemps/G temperatures for every chain ("walker").  Inside a block a swap
+// exchanges temperature LABELS of two local replicas (slot_of); at a block boundary the two ranks exchange the boundary
+// walkers' operator counts (4 B per chain and phase, ncclSend / ncclRecv in one group), both evaluate the same Philox-keyed
+// decision, and an accepted swap moves the two configurations (op-string up to the cutoff, p=0 state, counters, Philox
+// identity) through one more grouped send / receive.  Every rank therefore always holds exactly the configurations of its own
+// temperature block, and no collective touches the sweep path.  The transport is RCCL point-to-point on device buffers when a
+// communicator is attached (isingmc_pt_attach_nccl), otherwise the caller's host-staged sendrecv (tests: two ranks on one GPU).
+#include <dlfcn.h>
+
+struct PtState {
+    uint32_t ntemps = 0, nchains = 0, rank = 0, world = 1, tper = 0;
+    std::vector<double> betas;
+    uint64_t seed = 0, step = 0, total_swaps = 0;
+    std::vector<uint32_t> slot_of; // [R] global slot t*nchains + chain labelling local replica r
+    std::vector<uint32_t> rid;     // [R] configuration identity (global id it was created with)
+    uint32_t *d_rid = nullptr, *d_ham_row = nullptr;
+    isingmc_pt_transport tr{};
+    bool have_tr = false;
+    // RCCL, loaded on first use
+    void *nccl_lib = nullptr, *comm = nullptr;
+    int (*p_send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*p_recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*p_gstart)() = nullptr;
+    int (*p_gend)() = nullptr;
+    int (*p_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*p_init)(void **, int, isingmc_nccl_id, int) = nullptr;
+    int (*p_destroy)(void *) = nullptr;
+    uint32_t *d_small = nullptr; // [4][nchains] staging of the boundary operator counts / cutoffs on the device (RCCL path)
+    // different Hamiltonians per temperature (per-replica couplings): J rows of the neighbouring ranks' boundary slots
+    bool hams_differ = false;
+    std::vector<double> J_prev_last, J_next_first; // [nchains][E]
+    uint32_t *d_counts = nullptr;                  // [R][Nb] bond counts (only when hams_differ)
+    // configuration exchange
+    uint32_t *d_pack_s = nullptr, *d_pack_r = nullptr;
+    size_t pack_cap_words = 0;
+    std::vector<uint32_t> h_pack_s, h_pack_r;
+};
+
+static void pt_free(isingmc_batch *b) {
+    if (!b->pt) return;
+    PtState *P = b->pt;
+    if (P->comm && P->p_destroy) (void)P->p_destroy(P->comm);
+    for (void *q : {(void *)P->d_rid, (void *)P->d_ham_row, (void *)P->d_small, (void *)P->d_counts, (void *)P->d_pack_s, (void *)P->d_pack_r})
+        if (q) (void)hipFree(q);
+    delete P;
+    b->pt = nullptr;
+}
+
+// pack / unpack one configuration per workgroup: header (n, ntrans, cutoff, err, epoch lo/hi, rid, 0), p=0 state, chunk counters, op words
+#define PT_HDR 8u
+__global__ void pt_pack_kernel(DevBatch B, const uint32_t *rid, const uint32_t *items /*[nitems][3]: replica, word offset, cutoff*/, uint32_t *buf) {
+    const uint32_t r = items[3 * blockIdx.x], off = items[3 * blockIdx.x + 1], cut = items[3 * blockIdx.x + 2];
+    uint32_t *o = buf + off;
+    if (threadIdx.x == 0) {
+        o[0] = B.n[r]; o[1] = B.ntrans[r]; o[2] = B.cutoff[r]; o[3] = B.err[r];
+        o[4] = (uint32_t)B.epoch[r]; o[5] = (uint32_t)(B.epoch[r] >> 32); o[6] = rid[r]; o[7] = 0u;
+    }
+    for (uint32_t i = threadIdx.x; i < B.nwords; i += blockDim.x) o[PT_HDR + i] = B.state[(size_t)r * B.nwords + i];
+    for (uint32_t i = threadIdx.x; i < 2 * SSE_MAX_CHUNKS; i += blockDim.x) o[PT_HDR + B.nwords + i] = B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i];
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
+    for (uint32_t i = threadIdx.x; i < cut; i += blockDim.x) o[PT_HDR + B.nwords + 2 * SSE_MAX_CHUNKS + i] = ops[i];
+}
+__global__ void pt_unpack_kernel(DevBatch B, uint32_t *rid, const uint32_t *items, const uint32_t *buf) {
+    const uint32_t r = items[3 * blockIdx.x], off = items[3 * blockIdx.x + 1], cut = items[3 * blockIdx.x + 2];
+    const uint32_t *o = buf + off;
+    if (threadIdx.x == 0) {
+        B.n[r] = o[0]; B.ntrans[r] = o[1]; B.cutoff[r] = o[2]; B.err[r] = o[3];
+        B.epoch[r] = (uint64_t)o[4] | ((uint64_t)o[5] << 32); rid[r] = o[6];
+        if (B.lite) B.lite_epoch[r] = ~0ull;
+    }
+    for (uint32_t i = threadIdx.x; i < B.nwords; i += blockDim.x) B.state[(size_t)r * B.nwords + i] = o[PT_HDR + i];
+    for (uint32_t i = threadIdx.x; i < 2 * SSE_MAX_CHUNKS; i += blockDim.x) B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i] = o[PT_HDR + B.nwords + i];
+    uint32_t *ops = B.ops + (size_t)r * B.stride;
+    for (uint32_t i = threadIdx.x; i < cut; i += blockDim.x) ops[i] = o[PT_HDR + B.nwords + 2 * SSE_MAX_CHUNKS + i];
+}
+// OpContainer::get_count for every bond of every replica (op_container.rs:129): counts[r][bond]
+__global__ void pt_bond_count_kernel(DevBatch B, uint32_t *counts) {
+    const uint32_t r = blockIdx.x;
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
+    uint32_t *c = counts + (size_t)r * B.Nb;
+    for (uint32_t i = threadIdx.x; i < B.Nb; i += blockDim.x) c[i] = 0u;
+    __syncthreads();
+    const uint32_t M = B.cutoff[r];
+    for (uint32_t p = threadIdx.x; p < M; p += blockDim.x) { const uint32_t w = ops[p]; if (w) atomicAdd(&c[sse_op_bond(w)], 1u); }
+}
+
+static double pt_powi(double x, uint32_t n) { // x^n by squaring (the oracle uses the same multiplication sequence)
+    double r = 1.0;
+    while (n) { if (n & 1u) r *= x; x *= x; n >>= 1; }
+    return r;
+}
+// GraphWeights::relative_weight (tempering_traits.rs:126-155) for couplings that differ between temperature slots (the fields
+// are common to a batch): product over the edges of (J_to / J_from)^count, in edge order
+static double pt_relative_weight(const double *J_from, const double *J_to, const uint32_t *counts, uint32_t E) {
+    double w = 1.0;
+    for (uint32_t e = 0; e < E; ++e) w *= pt_powi(J_to[e] / J_from[e], counts[e]);
+    return w;
+}
+
+static int pt_exchange_small(isingmc_batch *b, int peer, const uint32_t *s, uint32_t *r, size_t count) {
+    PtState *P = b->pt;
+    if (peer < 0 || peer >= (int)P->world) return ISINGMC_OK;
+    if (P->comm) { // RCCL point-to-point on device buffers, one group call
+        uint32_t *ds = P->d_small, *dr = P->d_small + count;
+        HIP_TRY(b, hipMemcpyAsync(ds, s, 4 * count, hipMemcpyHostToDevice, b->stream));
+        if (P->p_gstart() || P->p_send(ds, count, /*ncclUint32*/ 3, peer, P->comm, b->stream) || P->p_recv(dr, count, 3, peer, P->comm, b->stream) || P->p_gend()) {
+            b->err = "RCCL send/recv failed"; return ISINGMC_ENODEVICE;
+        }
+        HIP_TRY(b, hipMemcpyAsync(r, dr, 4 * count, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(b, hipStreamSynchronize(b->stream));
+        return ISINGMC_OK;
+    }
+    if (!P->have_tr || P->tr.sendrecv(P->tr.ctx, peer, s, 4 * count, r, 4 * count)) { b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
+    return ISINGMC_OK;
+}
+
+extern "C" {
+
+int isingmc_pt_create(isingmc_batch *b, const isingmc_pt_layout *lay) {
+    if (!b || !lay || lay->struct_size != sizeof(isingmc_pt_layout) || !lay->betas || lay->ntemps == 0 || lay->nchains == 0 || lay->world == 0 ||
+        lay->rank >= lay->world || lay->ntemps % lay->world) { if (b) b->err = "bad tempering layout (temperatures must divide evenly over the ranks)"; return ISINGMC_EINVAL; }
+    const uint32_t tper = lay->ntemps / lay->world;
+    if ((size_t)tper * lay->nchains != b->dev.R) { b->err = "the batch must hold ntemps/world * nchains replicas"; return ISINGMC_EINVAL; }
+    if (lay->world > 1 && !lay->transport) { b->err = "a transport (or isingmc_pt_attach_nccl) is needed for more than one rank"; return ISINGMC_EINVAL; }
+    HIP_TRY(b, hipSetDevice(b->device));
+    pt_free(b);
+    PtState *P = new PtState();
+    b->pt = P;
+    P->ntemps = lay->ntemps; P->nchains = lay->nchains; P->rank = lay->rank; P->world = lay->world; P->tper = tper;
+    P->betas.assign(lay->betas, lay->betas + lay->ntemps);
+    P->seed = lay->seed;
+    if (lay->transport) { P->tr = *lay->transport; P->have_tr = true; }
+    const uint32_t R = b->dev.R;
+    P->slot_of.resize(R); P->rid.resize(R);
+    for (uint32_t r = 0; r < R; ++r) { P->slot_of[r] = P->rank * R + r; P->rid[r] = b->dev.replica_offset + r; }
+    HIP_TRY(b, hipMalloc((void **)&P->d_rid, 4 * (size_t)R));
+    HIP_TRY(b, hipMemcpy(P->d_rid, P->rid.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
+    b->dev.rid = P->d_rid;
+    HIP_TRY(b, hipMalloc((void **)&P->d_small, 4 * 4 * (size_t)(P->nchains * 2 + 2)));
+    P->pack_cap_words = (size_t)P->nchains * (PT_HDR + b->dev.nwords + 2 * SSE_MAX_CHUNKS + b->dev.cap);
+    HIP_TRY(b, hipMalloc((void **)&P->d_pack_s, 4 * P->pack_cap_words));
+    HIP_TRY(b, hipMalloc((void **)&P->d_pack_r, 4 * P->pack_cap_words));
+    if (b->per_replica_J) {
+        // different Hamiltonians between temperatures: the bond-table row belongs to the slot; neighbours' boundary rows once
+        P->hams_differ = true;
+        b->ham_row_host.resize(R);
+        for (uint32_t r = 0; r < R; ++r) b->ham_row_host[r] = r;
+        HIP_TRY(b, hipMalloc((void **)&P->d_ham_row, 4 * (size_t)R));
+        HIP_TRY(b, hipMemcpy(P->d_ham_row, b->ham_row_host.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
+        b->dev.ham_row = P->d_ham_row;
+        HIP_TRY(b, hipMalloc((void **)&P->d_counts, 4 * (size_t)R * b->dev.Nb));
+        const uint32_t E = b->dev.E, K = P->nchains;
+        auto Jrow = [&](uint32_t row, std::vector<double> &out, size_t at) { // J from the bond table: weight 2|J|, "prefers aligned" = J < 0
+            for (uint32_t e = 0; e < E; ++e) {
+                const BondRec &br = b->bonds_host[(size_t)row * b->dev.Nb + e];
+                out[at + e] = (((br.a_info >> (SSE_INFO_SHIFT + 2)) & 1u) ? -0.5 : 0.5) * br.w;
+            }
+        };
+        std::vector<double> first((size_t)K * E), last((size_t)K * E);
+        for (uint32_t k = 0; k < K; ++k) { Jrow(k, first, (size_t)k * E); Jrow((tper - 1) * K + k, last, (size_t)k * E); }
+        P->J_prev_last.assign((size_t)K * E, 0.0); P->J_next_first.assign((size_t)K * E, 0.0);
+        if (P->world > 1) {
+            const int prev = (int)P->rank - 1, next = (int)P->rank + 1;
+            if (prev >= 0 && P->tr.sendrecv(P->tr.ctx, prev, first.data(), 8 * first.size(), P->J_prev_last.data(), 8 * first.size())) { b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
+            if (next < (int)P->world && P->tr.sendrecv(P->tr.ctx, next, last.data(), 8 * last.size(), P->J_next_first.data(), 8 * last.size())) { b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
+        }
+    }
+    return ISINGMC_OK;
+}
+
+int isingmc_pt_nccl_unique_id(isingmc_nccl_id *out) {
+    if (!out) return ISINGMC_EINVAL;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return ISINGMC_ENODEVICE;
+    auto f = reinterpret_cast<int (*)(isingmc_nccl_id *)>(dlsym(lib, "ncclGetUniqueId"));
+    return (f && f(out) == 0) ? ISINGMC_OK : ISINGMC_ENODEVICE;
+}
+
+int isingmc_pt_attach_nccl(isingmc_batch *b, const isingmc_nccl_id *id) {
+    if (!b || !b->pt || !id) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    PtState *P = b->pt;
+    HIP_TRY(b, hipSetDevice(b->device));
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD); // the copy the process already uses (e.g. torch's), if any
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { b->err = "librccl.so not found"; return ISINGMC_ENODEVICE; }
+    P->nccl_lib = lib;
+    P->p_send = reinterpret_cast<decltype(P->p_send)>(dlsym(lib, "ncclSend"));
+    P->p_recv = reinterpret_cast<decltype(P->p_recv)>(dlsym(lib, "ncclRecv"));
+    P->p_gstart = reinterpret_cast<decltype(P->p_gstart)>(dlsym(lib, "ncclGroupStart"));
+    P->p_gend = reinterpret_cast<decltype(P->p_gend)>(dlsym(lib, "ncclGroupEnd"));
+    P->p_allreduce = reinterpret_cast<decltype(P->p_allreduce)>(dlsym(lib, "ncclAllReduce"));
+    P->p_init = reinterpret_cast<decltype(P->p_init)>(dlsym(lib, "ncclCommInitRank"));
+    P->p_destroy = reinterpret_cast<decltype(P->p_destroy)>(dlsym(lib, "ncclCommDestroy"));
+    if (!P->p_send || !P->p_recv || !P->p_gstart || !P->p_gend || !P->p_allreduce || !P->p_init) { b->err = "RCCL symbols missing"; return ISINGMC_ENODEVICE; }
+    if (P->p_init(&P->comm, (int)P->world, *id, (int)P->rank) != 0) { P->comm = nullptr; b->err = "ncclCommInitRank failed"; return ISINGMC_ENODEVICE; }
+    return ISINGMC_OK;
+}
+
+int isingmc_pt_get_slots(isingmc_batch *b, uint32_t *slot_of_replica, double *beta_of_replica, uint32_t *config_id_of_replica) {
+    if (!b || !b->pt) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    const PtState *P = b->pt;
+    for (uint32_t r = 0; r < b->dev.R; ++r) {
+        if (slot_of_replica) slot_of_replica[r] = P->slot_of[r];
+        if (beta_of_replica) beta_of_replica[r] = P->betas[P->slot_of[r] / P->nchains];
+        if (config_id_of_replica) config_id_of_replica[r] = P->rid[r];
+    }
+    return ISINGMC_OK;
+}
+
+// One tempering step of every chain (tempering_container.rs:121-149).  Adds the number of swaps this rank took part in
+// as the LOWER temperature's owner (so that the sum over ranks counts every swap once) to *nswaps.
+int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps) {
+    if (!b || !b->pt) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    PtState *P = b->pt;
+    HIP_TRY(b, hipSetDevice(b->device));
+    const uint32_t R = b->dev.R, K = P->nchains, T = P->ntemps, tper = P->tper, E = b->dev.E, Nb = b->dev.Nb;
+    const uint32_t t_lo = P->rank * tper, t_hi = t_lo + tper; // my temperature block [t_lo, t_hi)
+    const int prev = P->rank > 0 ? (int)P->rank - 1 : -1, next = P->rank + 1 < P->world ? (int)P->rank + 1 : -1;
+    uint64_t swaps = 0;
+    if (T <= 1) { P->step++; return ISINGMC_OK; }
+    std::vector<uint32_t> n(R), cut(R);
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    HIP_TRY(b, hipMemcpy(n.data(), b->dev.n, 4 * (size_t)R, hipMemcpyDeviceToHost));
+    HIP_TRY(b, hipMemcpy(cut.data(), b->dev.cutoff, 4 * (size_t)R, hipMemcpyDeviceToHost));
+    // replica at a local slot
+    std::vector<uint32_t> at(R);
+    auto rebuild_at = [&]() { for (uint32_t r = 0; r < R; ++r) at[P->slot_of[r] - t_lo * K] = r; };
+    rebuild_at();
+    // ---- equalise the cutoffs of every chain over all temperatures (:129-137): max over the ranks ----
+    std::vector<uint32_t> maxcut(K, 0u);
+    for (uint32_t r = 0; r < R; ++r) { const uint32_t k = P->slot_of[r] % K; if (cut[r] > maxcut[k]) maxcut[k] = cut[r]; }
+    if (P->world > 1) {
+        if (P->comm) {
+            HIP_TRY(b, hipMemcpyAsync(P->d_small, maxcut.data(), 4 * (size_t)K, hipMemcpyHostToDevice, b->stream));
+            if (P->p_allreduce(P->d_small, P->d_small, K, /*ncclUint32*/ 3, /*ncclMax*/ 2, P->comm, b->stream)) { b->err = "ncclAllReduce failed"; return ISINGMC_ENODEVICE; }
+            HIP_TRY(b, hipMemcpyAsync(maxcut.data(), P->d_small, 4 * (size_t)K, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(b, hipStreamSynchronize(b->stream));
+        } else if (P->tr.allreduce_max_u32(P->tr.ctx, maxcut.data(), K)) { b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
+    }
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t k = P->slot_of[r] % K;
+        if (maxcut[k] > b->dev.cap) { b->err = "cutoff exceeds capacity"; return ISINGMC_ECAPACITY; }
+        cut[r] = maxcut[k];
+    }
+    HIP_TRY(b, hipMemcpy(b->dev.cutoff, cut.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
+    std::vector<uint32_t> counts; // bond counts of every local configuration (only when the Hamiltonians differ between temperatures)
+    auto Jrow_local = [&](uint32_t row, uint32_t e) { const BondRec &br = b->bonds_host[(size_t)row * Nb + e]; return (((br.a_info >> (SSE_INFO_SHIFT + 2)) & 1u) ? -0.5 : 0.5) * br.w; };
+    std::vector<double> Ja(E), Jb(E);
+    // relative weight of local replica r (at local slot ls) towards the Hamiltonian of the slot above (+1) or below (-1)
+    auto relw = [&](uint32_t r, uint32_t ls, int dir) -> double {
+        if (!P->hams_differ) return 1.0;
+        const uint32_t k = ls % K, tl = ls / K;
+        for (uint32_t e = 0; e < E; ++e) Ja[e] = Jrow_local(ls, e);
+        if (dir > 0) { if (tl + 1 < tper) for (uint32_t e = 0; e < E; ++e) Jb[e] = Jrow_local(ls + K, e); else for (uint32_t e = 0; e < E; ++e) Jb[e] = P->J_next_first[(size_t)k * E + e]; }
+        else { if (tl > 0) for (uint32_t e = 0; e < E; ++e) Jb[e] = Jrow_local(ls - K, e); else for (uint32_t e = 0; e < E; ++e) Jb[e] = P->J_prev_last[(size_t)k * E + e]; }
+        return pt_relative_weight(Ja.data(), Jb.data(), counts.data() + (size_t)r * Nb, E);
+    };
+    // order coin per chain (gen_bool(0.5), :140)
+    const uint32_t key[2] = {(uint32_t)P->seed, (uint32_t)(P->seed >> 32)};
+    std::vector<uint8_t> a_first(K);
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t ctr[4] = {0u, (uint32_t)P->step, k, (SSE_TAG_PT << 24) | (uint32_t)((P->step >> 32) & 0xFFFFFFu)};
+        uint32_t o[4];
+        host_philox(ctr, key, o);
+        a_first[k] = (o[0] >> 31) != 0u;
+    }
+    auto decide = [&](uint32_t k, uint32_t t, uint32_t na, uint32_t nb2, double ra, double rb) -> bool {
+        const uint32_t ctr[4] = {1u + t, (uint32_t)P->step, k, (SSE_TAG_PT << 24) | (uint32_t)((P->step >> 32) & 0xFFFFFFu)};
+        uint32_t o[4];
+        host_philox(ctr, key, o);
+        const double u = (double)o[0] * (1.0 / 4294967296.0);
+        const double dn = (double)((int64_t)nb2 - (int64_t)na);
+        double p = std::pow(P->betas[t] / P->betas[t + 1], dn); // swap_on_chunks (:296-298)
+        if (P->hams_differ) p *= ra * rb;
+        return p > u;
+    };
+    struct Wire { uint32_t n; uint32_t pad; double rel; };
+    for (int phase = 0; phase < 2; ++phase) {
+        if (P->hams_differ) { // (again in the second phase: a boundary swap of the first one replaced configurations)
+            hipLaunchKernelGGL(pt_bond_count_kernel, dim3(R), dim3(256), 0, b->stream, b->dev, P->d_counts);
+            counts.resize((size_t)R * Nb);
+            HIP_TRY(b, hipMemcpyAsync(counts.data(), P->d_counts, 4 * counts.size(), hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(b, hipStreamSynchronize(b->stream));
+        }
+        // boundary walkers of this phase: for chain k the pair (t, t+1) is in the phase's set iff (t even) == (set a)
+        auto in_set = [&](uint32_t k, uint32_t t) { const bool set_a = (phase == 0) ? a_first[k] : !a_first[k]; return ((t & 1u) == 0u) == set_a; };
+        // ---- exchange the operator counts (and relative weights) of the boundary walkers with both neighbours ----
+        std::vector<Wire> s_prev(K), r_prev(K), s_next(K), r_next(K);
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t rf = at[k], rl = at[(tper - 1) * K + k];
+            s_prev[k] = {n[rf], 0u, prev >= 0 ? relw(rf, k, -1) : 1.0};
+            s_next[k] = {n[rl], 0u, next >= 0 ? relw(rl, (tper - 1) * K + k, +1) : 1.0};
+        }
+        static_assert(sizeof(Wire) == 16, "wire format");
+        int rc;
+        // (even ranks talk to their upper neighbour first: the host-staged transport is blocking)
+        for (int turn = 0; turn < 2; ++turn) {
+            const bool up = ((P->rank & 1u) == 0u) == (turn == 0);
+            if (up) { if ((rc = pt_exchange_small(b, next, reinterpret_cast<const uint32_t *>(s_next.data()), reinterpret_cast<uint32_t *>(r_next.data()), 4 * (size_t)K))) return rc; }
+            else if ((rc = pt_exchange_small(b, prev, reinterpret_cast<const uint32_t *>(s_prev.data()), reinterpret_cast<uint32_t *>(r_prev.data()), 4 * (size_t)K))) return rc;
+        }
+        // ---- decisions ----
+        std::vector<uint32_t> items_next, items_prev; // accepted boundary swaps: (replica, word offset in the message, cutoff)
+        size_t off_next = 0, off_prev = 0;
+        for (uint32_t k = 0; k < K; ++k) {
+            // interior pairs
+            for (uint32_t t = t_lo; t + 1 < t_hi; ++t) {
+                if (!in_set(k, t)) continue;
+                const uint32_t la = (t - t_lo) * K + k, lb = la + K;
+                const uint32_t ra_ = at[la], rb_ = at[lb];
+                if (decide(k, t, n[ra_], n[rb_], relw(ra_, la, +1), relw(rb_, lb, -1))) {
+                    std::swap(P->slot_of[ra_], P->slot_of[rb_]);
+                    at[la] = rb_; at[lb] = ra_;
+                    swaps++;
+                }
+            }
+            const size_t words = PT_HDR + b->dev.nwords + 2 * SSE_MAX_CHUNKS + maxcut[k];
+            // boundary pair with the next rank: (t_hi - 1, t_hi)
+            if (next >= 0 && in_set(k, t_hi - 1)) {
+                const uint32_t la = (tper - 1) * K + k, ra_ = at[la];
+                if (decide(k, t_hi - 1, n[ra_], r_next[k].n, s_next[k].rel, r_next[k].rel)) {
+                    items_next.insert(items_next.end(), {ra_, (uint32_t)off_next, maxcut[k]});
+                    off_next += words;
+                    n[ra_] = r_next[k].n;
+                    swaps++; // counted by the owner of the lower temperature
+                }
+            }
+            // boundary pair with the previous rank: (t_lo - 1, t_lo)
+            if (prev >= 0 && in_set(k, t_lo - 1)) {
+                const uint32_t rb_ = at[k];
+                if (decide(k, t_lo - 1, r_prev[k].n, n[rb_], r_prev[k].rel, s_prev[k].rel)) {
+                    items_prev.insert(items_prev.end(), {rb_, (uint32_t)off_prev, maxcut[k]});
+                    off_prev += words;
+                    n[rb_] = r_prev[k].n;
+                }
+            }
+        }
+        // ---- accepted boundary swaps: the two configurations change ranks ----
+        for (int turn = 0; turn < 2; ++turn) {
+            const bool up = ((P->rank & 1u) == 0u) == (turn == 0);
+            const std::vector<uint32_t> &items = up ? items_next : items_prev;
+            const size_t words = up ? off_next : off_prev;
+            const int peer = up ? next : prev;
+            if (peer < 0 || items.empty()) continue;
+            const uint32_t nitems = (uint32_t)(items.size() / 3);
+            uint32_t *d_it = nullptr;
+            HIP_TRY(b, hipMalloc((void **)&d_it, 4 * items.size()));
+            HIP_TRY(b, hipMemcpyAsync(d_it, items.data(), 4 * items.size(), hipMemcpyHostToDevice, b->stream));
+            hipLaunchKernelGGL(pt_pack_kernel, dim3(nitems), dim3(256), 0, b->stream, b->dev, P->d_rid, d_it, P->d_pack_s);
+            if (P->comm) {
+                if (P->p_gstart() || P->p_send(P->d_pack_s, words, 3, peer, P->comm, b->stream) || P->p_recv(P->d_pack_r, words, 3, peer, P->comm, b->stream) || P->p_gend()) {
+                    (void)hipFree(d_it); b->err = "RCCL send/recv failed"; return ISINGMC_ENODEVICE;
+                }
+            } else {
+                P->h_pack_s.resize(words); P->h_pack_r.resize(words);
+                HIP_TRY(b, hipMemcpyAsync(P->h_pack_s.data(), P->d_pack_s, 4 * words, hipMemcpyDeviceToHost, b->stream));
+                HIP_TRY(b, hipStreamSynchronize(b->stream));
+                if (P->tr.sendrecv(P->tr.ctx, peer, P->h_pack_s.data(), 4 * words, P->h_pack_r.data(), 4 * words)) { (void)hipFree(d_it); b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
+                HIP_TRY(b, hipMemcpyAsync(P->d_pack_r, P->h_pack_r.data(), 4 * words, hipMemcpyHostToDevice, b->stream));
+            }
+            hipLaunchKernelGGL(pt_unpack_kernel, dim3(nitems), dim3(256), 0, b->stream, b->dev, P->d_rid, d_it, P->d_pack_r);
+            HIP_TRY(b, hipStreamSynchronize(b->stream));
+            (void)hipFree(d_it);
+        }
+        if (!items_next.empty() || !items_prev.empty()) HIP_TRY(b, hipMemcpy(P->rid.data(), P->d_rid, 4 * (size_t)R, hipMemcpyDeviceToHost));
+    }
+    if (P->hams_differ) { // the bond-table row follows the slot
+        for (uint32_t r = 0; r < R; ++r) b->ham_row_host[r] = P->slot_of[r] - t_lo * K;
+        HIP_TRY(b, hipMemcpy(P->d_ham_row, b->ham_row_host.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
+    }
+    P->step++;
+    P->total_swaps += swaps;
+    if (nswaps) *nswaps += swaps;
     return ISINGMC_OK;
 }
 

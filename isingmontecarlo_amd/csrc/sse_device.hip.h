@@ -70,6 +70,11 @@ struct DevBatch {
     uint8_t *tbl;         // [R][tbl_stride] per-variable tables in HBM/L2 for models whose tables exceed LDS (MODE 2, see Tab)
     uint32_t tbl_stride;  // bytes per replica: Wmax*N*2 (cut ranks / spin bytes) + Wmax*N (cut markers) + N (touched), rounded up to 16
     uint32_t seed_lo, seed_hi, replica_offset;
+    const uint32_t *rid;     // [R] or null: identity of the configuration held by each local replica = the `replica` word of its Philox
+                             // counters (null: replica_offset + r).  Parallel tempering moves configurations between ranks at
+                             // temperature-block boundaries; their random streams move with them
+    const uint32_t *ham_row; // [R] or null: with per-replica couplings, the row of the bond tables a replica runs with (null: r).
+                             // Tempering between different Hamiltonians: the row belongs to the temperature slot, not the configuration
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
     uint32_t lds_words;   // dynamic LDS words available to the workgroup
     const double *mats;   // generic interactions (Qmc, qmc_runner.rs:415-680): [Nb][16] weights indexed in | out<<2; NULL = Ising bonds
@@ -149,7 +154,7 @@ struct Rng {
 };
 __device__ __forceinline__ Rng make_rng(const DevBatch &B, uint32_t r, uint64_t epoch) {
     Rng g;
-    g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.replica_offset + r;
+    g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.rid ? B.rid[r] : B.replica_offset + r;
     g.epoch_lo = (uint32_t)epoch; g.epoch_hi24 = (uint32_t)(epoch >> 32) & 0xFFFFFFu;
 #ifdef SSE_PHASE_TIMING
     g.dbgx = B.dbg_flags;
@@ -1469,9 +1474,10 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
     if (B.bond_stride) { // per-replica couplings: this replica's tables (B is this workgroup's private copy)
-        B.bonds += (size_t)r * B.bond_stride;
-        B.cumw += (size_t)r * B.bond_stride;
-        B.wtot = B.wtot_r[r];
+        const uint32_t hr = B.ham_row ? B.ham_row[r] : r;
+        B.bonds += (size_t)hr * B.bond_stride;
+        B.cumw += (size_t)hr * B.bond_stride;
+        B.wtot = B.wtot_r[hr];
     }
     for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_state, i) = B.state[(size_t)r * B.nwords + i];
     if constexpr (CL)

@@ -505,7 +505,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
 
     for (uint32_t attempt = 0; attempt < updates; ++attempt) {
         RvbDraw g;
-        g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.replica_offset + r; g.epoch_lo = (uint32_t)epoch; g.attempt = attempt; g.k = 0;
+        g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.rid ? B.rid[r] : B.replica_offset + r; g.epoch_lo = (uint32_t)epoch; g.attempt = attempt; g.k = 0;
         // ================= phase A (sequential lane): start, cluster growth, sub-variables, windows =================
         if (tid == 0) {
             uint32_t lerr = 0;

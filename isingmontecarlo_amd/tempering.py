@@ -171,3 +171,117 @@ class TemperingContainer:
 
     def verify(self):
         return bool(np.all(self.b.verify()))
+
+
+class NativeTemperingContainer:
+    """TemperingContainer (tempering_container.rs) over the library's native step, isingmc_pt_step: temperature blocks
+    sharded over ranks, label swaps inside a block, point-to-point exchange of the boundary walkers between neighbouring
+    ranks (RCCL ncclSend / ncclRecv after attach_rccl(); otherwise torch.distributed send / recv staged through host memory,
+    which is what the tests use for two ranks on one GPU).  `graph` is this rank's QmcIsingGraph holding
+    len(betas) / world * nchains replicas, built with replica_offset = rank * nreplicas.  With per-replica couplings the
+    rows of `couplings` belong to the temperature slots and swaps weigh the two Hamiltonians (tempering_traits.rs:126-155)."""
+
+    def __init__(self, graph, betas, nchains, seed, flags=0):
+        from . import _PtLayout, _PtTransport, _PT_SENDRECV, _PT_ALLMAX
+        self.g = graph
+        self.betas = np.ascontiguousarray(np.asarray(betas, dtype=np.float64))
+        self.ntemps, self.nchains, self.flags = len(self.betas), int(nchains), int(flags)
+        self.dist = None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                self.dist = dist
+        except Exception:
+            self.dist = None
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self._cb = (_PT_SENDRECV(self._sendrecv), _PT_ALLMAX(self._allmax))  # keep the callbacks alive
+        self._tr = _PtTransport(ctx=None, sendrecv=self._cb[0], allreduce_max_u32=self._cb[1])
+        lay = _PtLayout(struct_size=C.sizeof(_PtLayout), ntemps=self.ntemps, nchains=self.nchains, rank=self.rank, world=self.world,
+                        betas=self.betas.ctypes.data_as(C.POINTER(C.c_double)), seed=int(seed),
+                        transport=C.pointer(self._tr) if self.world > 1 else None)
+        graph._check(graph._lib.isingmc_pt_create(graph._h, C.byref(lay)))
+        self.total_swaps_local = 0
+        self._refresh()
+
+    # ---- host-staged transport over torch.distributed (CPU tensors with gloo, device tensors with nccl) ----
+    def _tensor_dev(self):
+        return "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+
+    def _sendrecv(self, ctx, peer, sbuf, sbytes, rbuf, rbytes):
+        try:
+            import torch
+            ts = torch.from_numpy(np.ctypeslib.as_array(C.cast(sbuf, C.POINTER(C.c_uint8)), shape=(sbytes,)).copy()).to(self._tensor_dev())
+            tr = torch.empty(rbytes, dtype=torch.uint8, device=self._tensor_dev())
+            ops = [self.dist.P2POp(self.dist.isend, ts, peer), self.dist.P2POp(self.dist.irecv, tr, peer)]
+            if self.rank > peer:
+                ops.reverse()
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+            C.memmove(rbuf, tr.cpu().numpy().ctypes.data, rbytes)
+            return 0
+        except Exception as e:  # never unwind through the C caller
+            print("tempering transport:", e)
+            return 1
+
+    def _allmax(self, ctx, buf, count):
+        try:
+            import torch
+            a = np.ctypeslib.as_array(buf, shape=(count,))
+            t = torch.from_numpy(a.astype(np.int64)).to(self._tensor_dev())
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            a[:] = t.cpu().numpy().astype(np.uint32)
+            return 0
+        except Exception as e:
+            print("tempering transport:", e)
+            return 1
+
+    def attach_rccl(self):
+        """Create the library's own RCCL communicator (ncclCommInitRank; the id travels through torch.distributed) so that
+        the neighbour exchange runs as ncclSend / ncclRecv on device buffers.  Needs one rank per GPU."""
+        from . import _NcclId
+        import torch
+        nid = _NcclId()
+        if self.rank == 0:
+            self.g._check(self.g._lib.isingmc_pt_nccl_unique_id(C.byref(nid)))
+        t = torch.frombuffer(bytearray(C.string_at(C.byref(nid), 128)), dtype=torch.uint8).clone().to(self._tensor_dev() if self.dist else "cpu")
+        if self.dist:
+            self.dist.broadcast(t, src=0)
+        C.memmove(C.byref(nid), t.cpu().numpy().ctypes.data, 128)
+        self.g._check(self.g._lib.isingmc_pt_attach_nccl(self.g._h, C.byref(nid)))
+
+    # ---- labels ----
+    def _refresh(self):
+        R = self.g.nreplicas
+        self.slot_of = np.zeros(R, dtype=np.uint32)
+        self.local_betas = np.zeros(R, dtype=np.float64)
+        self.config_of = np.zeros(R, dtype=np.uint32)
+        self.g._check(self.g._lib.isingmc_pt_get_slots(self.g._h, self.slot_of.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                         self.local_betas.ctypes.data_as(C.POINTER(C.c_double)),
+                                                         self.config_of.ctypes.data_as(C.POINTER(C.c_uint32))))
+        self.g.set_accumulator_rows(self.ntemps * self.nchains, self.slot_of)
+
+    # ---- reference API ----
+    def num_graphs(self):
+        return self.ntemps * self.nchains
+
+    def timesteps(self, t, sampling_freq=1):
+        self.g.run(int(t), self.local_betas, sampling_freq, self.flags)
+
+    def tempering_step(self):
+        sw = C.c_uint64(0)
+        self.g._check(self.g._lib.isingmc_pt_step(self.g._h, C.byref(sw)))
+        self.total_swaps_local += int(sw.value)
+        self._refresh()
+        return int(sw.value)
+
+    def get_total_swaps(self):
+        if not self.dist:
+            return self.total_swaps_local
+        import torch
+        t = torch.tensor([self.total_swaps_local], dtype=torch.int64, device=self._tensor_dev())
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def verify(self):
+        return bool(np.all(self.g.verify()))

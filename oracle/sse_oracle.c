@@ -619,6 +619,7 @@ int ora_set_cutoff(ora_replica *r, uint32_t cutoff) {
     return 0;
 }
 uint64_t ora_get_epoch(const ora_replica *r) { return r->epoch; }
+void ora_set_epoch(ora_replica *r, uint64_t epoch) { r->epoch = epoch; } /* tests: a configuration moved into another replica object */
 void ora_get_state(const ora_replica *r, uint8_t *out) { memcpy(out, r->state, r->m->nvars); }
 void ora_set_state(ora_replica *r, const uint8_t *in) {
     for (uint32_t v = 0; v < r->m->nvars; ++v) r->state[v] = in[v] ? 1 : 0;

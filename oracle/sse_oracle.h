@@ -74,6 +74,7 @@ uint32_t ora_get_n(const ora_replica *r);
 uint32_t ora_get_cutoff(const ora_replica *r);
 int ora_set_cutoff(ora_replica *r, uint32_t cutoff);
 uint64_t ora_get_epoch(const ora_replica *r);
+void ora_set_epoch(ora_replica *r, uint64_t epoch);
 void ora_get_state(const ora_replica *r, uint8_t *out);
 void ora_set_state(ora_replica *r, const uint8_t *in);
 void ora_get_ops(const ora_replica *r, uint32_t *out /* cutoff words */);

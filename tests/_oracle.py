@@ -44,6 +44,7 @@ def load():
         "ora_get_cutoff": (u32, [vp]),
         "ora_set_cutoff": (C.c_int, [vp, u32]),
         "ora_get_epoch": (u64, [vp]),
+        "ora_set_epoch": (None, [vp, u64]),
         "ora_get_state": (None, [vp, p(C.c_uint8)]),
         "ora_set_state": (None, [vp, p(C.c_uint8)]),
         "ora_get_ops": (None, [vp, p(u32)]),
@@ -202,6 +203,9 @@ class Replica:
     @property
     def epoch(self):
         return lib().ora_get_epoch(self.ptr)
+
+    def set_epoch(self, e):
+        lib().ora_set_epoch(self.ptr, int(e))
 
     def state(self):
         out = np.zeros(self.model.nvars, dtype=np.uint8)

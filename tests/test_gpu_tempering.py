@@ -1,0 +1,140 @@
+"""GPU tests of the native tempering step (isingmc_pt_create / isingmc_pt_step): label swaps inside a temperature block,
+configuration exchange between neighbouring ranks, relative Hamiltonian weights — against the oracle's graph-swapping
+restatement of TemperingContainer::tempering_step (tempering_container.rs:121-149,241-302)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _lattices as lat
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+BETAS = np.array([0.5, 0.8, 1.1, 1.5, 2.0, 2.6])
+K, SEED, STEPS, SWEEPS = 4, 2468, 15, 2
+
+
+def oracle_reference(oracle):
+    from test_tempering_cpu import reference_pt
+    e, j = lat.split(lat.two_d_periodic(4))
+    m = oracle.Model(16, e, j, 1.0, 0.0)
+    return reference_pt(m, BETAS, K, SEED, 4096, 16, nsteps=STEPS, sweeps_per_step=SWEEPS)
+
+
+def test_native_step_single_rank_matches_oracle(oracle):
+    import isingmontecarlo_amd as im
+    by_slot, swaps_ref = oracle_reference(oracle)
+    g = im.QmcIsingGraph(lat.two_d_periodic(4), 1.0, 0.0, 16, SEED, nreplicas=len(BETAS) * K, capacity=4096)
+    tc = im.NativeTemperingContainer(g, BETAS, K, SEED)
+    for _ in range(STEPS):
+        tc.timesteps(SWEEPS)
+        tc.tempering_step()
+    assert tc.get_total_swaps() == swaps_ref and swaps_ref > 0
+    st, n, cut = g.state_ref(), g.get_n(), g.get_cutoff()
+    for r in range(g.nreplicas):
+        t, k = divmod(int(tc.slot_of[r]), K)
+        ref = by_slot[k][t]
+        assert n[r] == ref.n and cut[r] == ref.cutoff
+        assert np.array_equal(st[r], ref.state()) and np.array_equal(g.export_ops(r), ref.ops())
+    assert tc.verify()
+    acc = g.accumulators()
+    assert acc.shape == (len(BETAS) * K, 8) and (acc[:, 1] == STEPS * SWEEPS).all()
+
+
+@pytest.mark.timeout(600)
+def test_native_step_two_ranks_exchange_configurations(oracle, tmp_path):
+    """Two ranks (both on GPU 0), three temperatures each: swaps across the block boundary move whole configurations between
+    the processes (op-string, state, counters, Philox identity).  The union of both ranks equals the oracle's single chain."""
+    by_slot, swaps_ref = oracle_reference(oracle)
+    out = str(tmp_path / "pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(HERE, "_pt_native_worker.py"), out]
+    subprocess.check_call(cmd, env=env, cwd=os.path.dirname(HERE), timeout=500)
+    moved = 0
+    for rank in range(2):
+        z = np.load(out + f".rank{rank}.npz")
+        assert bool(z["ok"]) and int(z["swaps"]) == swaps_ref
+        per = len(z["n"])
+        for r in range(per):
+            t, k = divmod(int(z["slot_of"][r]), K)
+            assert rank * 3 <= t < rank * 3 + 3  # a rank only ever holds its own temperatures
+            ref = by_slot[k][t]
+            assert int(z["n"][r]) == ref.n and int(z["cutoff"][r]) == ref.cutoff
+            assert np.array_equal(z["state"][r], ref.state())
+            assert np.array_equal(z["ops"][r][:ref.cutoff], ref.ops())
+            moved += int(z["config_of"][r]) // (3 * K) != rank  # configuration that started on the other rank
+        assert (z["acc"][:, 1].reshape(len(BETAS), K)[rank * 3:rank * 3 + 3] == STEPS * SWEEPS).all()
+    assert moved > 0
+
+
+def _powi(x, n):
+    r = 1.0
+    while n:
+        if n & 1:
+            r *= x
+        x *= x
+        n >>= 1
+    return r
+
+
+def test_relative_weights_between_different_hamiltonians(oracle):
+    """tempering_container.rs:830-858 test_bondstrength: nine graphs on one chain, couplings j * i / 10 (i = 1..9), the same beta:
+    swaps are decided by GraphWeights::relative_weight alone (tempering_traits.rs:126-155).  Oracle side: configurations
+    (op-string, state, update counter, Philox identity) are moved between replica objects built on the slots' models."""
+    import isingmontecarlo_amd as im
+    edges = [((0, 1), 1.0), ((1, 2), 1.0), ((2, 3), 1.0), ((3, 4), 1.0)]
+    T, beta, gamma, seed, cap, steps = 9, 10.0, 0.1, 31415, 2048, 12
+    J = np.array([[j * i / 10.0 for _, j in edges] for i in range(1, T + 1)])
+    betas = np.full(T, beta)
+    g = im.QmcIsingGraph(edges, gamma, 0.0, 10, seed, nreplicas=T, capacity=cap, couplings=J)
+    tc = im.NativeTemperingContainer(g, betas, 1, seed)
+    e = [list(ab) for ab, _ in edges]
+    models = [oracle.Model(5, e, list(J[t]), gamma, 0.0) for t in range(T)]
+    reps = [oracle.Replica(models[t], cap, 10, seed, t) for t in range(T)]
+    ids = list(range(T))  # configuration identity at each slot
+    key = (seed & 0xFFFFFFFF, seed >> 32)
+    import ctypes as C
+    def philox(idx, step):
+        ctr = (C.c_uint32 * 4)(idx, step, 0, 6 << 24); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+        oracle.lib().ora_philox4x32_10(ctr, k, o)
+        return o[0]
+    swaps_ref = 0
+    for step in range(steps):
+        tc.timesteps(20)
+        for t in range(T):
+            reps[t].timesteps(20, beta)
+        tc.tempering_step()
+        # ---- reference formulation with relative weights ----
+        maxcut = max(r.cutoff for r in reps)
+        for r in reps:
+            assert r.set_cutoff(maxcut) == 0
+        a_first = (philox(0, step) >> 31) != 0
+        for phase in range(2):
+            set_a = a_first if phase == 0 else not a_first
+            for t in range(0 if set_a else 1, T - 1, 2):
+                u = philox(1 + t, step) / 4294967296.0
+                ga, gb = reps[t], reps[t + 1]
+                rel_b = 1.0
+                for b_ in range(len(edges)):
+                    rel_b *= _powi(J[t + 1][b_] / J[t][b_], ga.bond_count(b_))
+                rel_a = 1.0
+                for b_ in range(len(edges)):
+                    rel_a *= _powi(J[t][b_] / J[t + 1][b_], gb.bond_count(b_))
+                p = (betas[t] / betas[t + 1]) ** float(gb.n - ga.n) * (rel_b * rel_a)
+                if p > u:
+                    swaps_ref += 1
+                    na = oracle.Replica(models[t], cap, maxcut, seed, ids[t + 1], gb.state()); na.set_ops(gb.ops()); na.set_epoch(gb.epoch)
+                    nb = oracle.Replica(models[t + 1], cap, maxcut, seed, ids[t], ga.state()); nb.set_ops(ga.ops()); nb.set_epoch(ga.epoch)
+                    reps[t], reps[t + 1] = na, nb
+                    ids[t], ids[t + 1] = ids[t + 1], ids[t]
+    assert tc.get_total_swaps() == swaps_ref and swaps_ref > 0
+    st, n = g.state_ref(), g.get_n()
+    for r in range(T):
+        t = int(tc.slot_of[r])
+        assert int(tc.config_of[r]) == ids[t]
+        assert n[r] == reps[t].n and np.array_equal(st[r], reps[t].state()) and np.array_equal(g.export_ops(r), reps[t].ops())
+    assert tc.verify() and all(r.verify() for r in reps)
