@@ -183,6 +183,9 @@ int isingmc_get_bond_count(isingmc_batch *b, uint32_t r, uint32_t bond, uint32_t
 int isingmc_export_ops(isingmc_batch *b, uint32_t r, uint32_t *words, uint32_t nwords);
 /* FastOps::new_from_ops (fast_ops.rs:80-174): install an op-string (words[nwords], slot p = index) */
 int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint32_t nwords);
+/* DebugOps::count_diagonal_and_off and count_constant_ops (qmc_debug.rs:10-41) for every replica: out[R][3] = diagonal ops,
+ * off-diagonal ops (their sum is get_n), constant ops */
+int isingmc_debug_counts(isingmc_batch *b, uint32_t *out);
 /* Verify::verify (qmc_ising.rs:829-860; op_container.rs:137-159), ok[R] */
 int isingmc_verify(isingmc_batch *b, uint8_t *ok);
 
@@ -238,6 +241,11 @@ int isingmc_pt_attach_nccl(isingmc_batch *b, const isingmc_nccl_id *id);
 int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps);
 /* current labels of the local replicas: global slot (t * nchains + chain), its beta, and the configuration's identity */
 int isingmc_pt_get_slots(isingmc_batch *b, uint32_t *slot_of_replica, double *beta_of_replica, uint32_t *config_id_of_replica);
+
+/* container-level save / load (the reference serialises the whole container, tempering_container.rs:683-792): labels, configuration
+ * identities, step counter and swap count; the replicas themselves travel through export_ops / get_state / get_epoch */
+int isingmc_pt_get_state(isingmc_batch *b, uint64_t *step, uint64_t *total_swaps);
+int isingmc_pt_set_state(isingmc_batch *b, const uint32_t *slot_of_replica, const uint32_t *config_id_of_replica, uint64_t step, uint64_t total_swaps);
 
 /* stream plumbing: use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
 int isingmc_set_stream(isingmc_batch *b, void *hip_stream);

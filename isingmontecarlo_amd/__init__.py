@@ -101,6 +101,7 @@ SYMBOLS = {
     "isingmc_export_ops": (C.c_int, [_vp, _u32, _P(_u32), _u32]),
     "isingmc_import_ops": (C.c_int, [_vp, _u32, _P(_u32), _u32]),
     "isingmc_verify": (C.c_int, [_vp, _P(C.c_uint8)]),
+    "isingmc_debug_counts": (C.c_int, [_vp, _P(_u32)]),
     "isingmc_pt_decide": (C.c_int, [_u64, _u64, _u32, _u32, _P(_f64), _P(_u32), _P(_u32), _P(_u64)]),
     "isingmc_set_cutoffs": (C.c_int, [_vp, _P(_u32)]),
     "isingmc_pt_create": (C.c_int, [_vp, _P(_PtLayout)]),
@@ -108,6 +109,8 @@ SYMBOLS = {
     "isingmc_pt_attach_nccl": (C.c_int, [_vp, _P(_NcclId)]),
     "isingmc_pt_step": (C.c_int, [_vp, _P(_u64)]),
     "isingmc_pt_get_slots": (C.c_int, [_vp, _P(_u32), _P(_f64), _P(_u32)]),
+    "isingmc_pt_get_state": (C.c_int, [_vp, _P(_u64), _P(_u64)]),
+    "isingmc_pt_set_state": (C.c_int, [_vp, _P(_u32), _P(_u32), _u64, _u64]),
     "isingmc_set_accumulator_rows": (C.c_int, [_vp, _u32, _P(_u32)]),
     "isingmc_set_stream": (C.c_int, [_vp, _vp]),
     "isingmc_set_steps_per_launch": (C.c_int, [_vp, _u64]),
@@ -495,6 +498,20 @@ class QmcIsingGraph:
     def clear_errors(self):
         """Clear the sticky per-replica device error flags (ECAPACITY / ELIMIT / EINTEGRITY)."""
         self._check(self._lib.isingmc_clear_errors(self._h))
+
+    def count_diagonal_and_off(self):
+        """QmcDebug::count_diagonal_and_off (qmc_debug.rs:50-52): (diagonal, off-diagonal) op counts per replica."""
+        c = self._debug_counts()
+        return c[:, 0], c[:, 1]
+
+    def count_constant_ops(self):
+        """QmcDebug::count_constant_ops (qmc_debug.rs:54-56)."""
+        return self._debug_counts()[:, 2]
+
+    def _debug_counts(self):
+        out = np.zeros((self.nreplicas, 3), dtype=np.uint32)
+        self._check(self._lib.isingmc_debug_counts(self._h, _ptr(out, C.c_uint32)))
+        return out
 
     def verify(self):
         out = np.zeros(self.nreplicas, dtype=np.uint8)

@@ -181,6 +181,28 @@ __global__ __launch_bounds__(256) void itime_magnetization_kernel(DevBatch B, lo
     }
 }
 
+// DebugOps::count_diagonal_and_off / count_constant_ops (qmc_debug.rs:10-41): one workgroup per replica, out[r] = {diagonal,
+// off-diagonal, constant} ops among the slots below the cutoff
+__global__ __launch_bounds__(256) void debug_counts_kernel(DevBatch B, uint32_t *out) {
+    __shared__ uint32_t red[3];
+    const uint32_t r = blockIdx.x;
+    if (threadIdx.x < 3) red[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
+    const uint32_t M = B.cutoff[r];
+    const BondRec *bonds = B.bonds + (size_t)(B.bond_stride ? (B.ham_row ? B.ham_row[r] : r) : 0u) * B.bond_stride;
+    uint32_t d = 0, o = 0, c = 0;
+    for (uint32_t p = threadIdx.x; p < M; p += blockDim.x) {
+        const uint32_t w = ops[p];
+        if (!w) continue;
+        if (sse_op_is_diagonal(w)) d++; else o++;
+        if (((bonds[sse_op_bond(w)].a_info >> SSE_INFO_SHIFT) & SSE_BOND_KIND_MASK) == SSE_BOND_TRANSVERSE) c++; // BasicOp::constant
+    }
+    atomicAdd(&red[0], d); atomicAdd(&red[1], o); atomicAdd(&red[2], c);
+    __syncthreads();
+    if (threadIdx.x < 3) out[3 * r + threadIdx.x] = red[threadIdx.x];
+}
+
 static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, bool tg = false) {
     // mirrors Lds<W>::carve up to and including o_cl: state, touched bits, touched bytes, round buffers, misc, chunk counters,
     // edge table, per-wave rank tables (u16) and marker tables (u8); with the tables in HBM (tg) only the bit arrays remain
@@ -354,7 +376,9 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             b->last_W_off = 16;
         }
     }
-    if (loop_only) lc.passes = SSE_PASSES_DIAG; // a lone directed loop uses the small launch geometry too
+    const bool rvb_only = (A.domask & ~SSE_DO_GROW) == SSE_DO_RVB;
+    if (rvb_only) lc.passes = SSE_PASSES_RVB;   // the RVB sweep alone: its own kernel (no scratch spills, unlike the all-passes kernel)
+    else if (loop_only) lc.passes = SSE_PASSES_DIAG; // a lone directed loop uses the small launch geometry too
     else if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB | SSE_DO_LOOP)) || (split && !(A.domask & SSE_DO_RVB))) {
         lc.passes = SSE_PASSES_OFFDIAG;
         plan_offdiag();
@@ -403,9 +427,30 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             launches++; b->pass_launches[0]++;
             if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done + 1], b->stream));
             const bool sample = freq && (done + 1) % freq == 0;
-            if (rest || sample) {
+            uint32_t rest2 = rest;
+            if ((rest & SSE_DO_RVB) && !(rest & SSE_DO_LOOP)) {
+                // the RVB sweep as its own launch (register budget of its own: the all-passes kernel spills to scratch), then the
+                // cluster / free-spin launch in its usual geometry
+                SweepArgs ar = A;
+                ar.domask = SSE_DO_RVB; ar.nsteps = 1; ar.step0 = done; ar.sampling_freq = 0; ar.out_u32 = nullptr;
+                LaunchCfg lr = lc;
+                lr.passes = SSE_PASSES_RVB;
+                e = launch_dev(lr, use_dev_off ? dev_off : b->dev, ar);
+                if (e != hipSuccess) return fail_launch(e);
+                launches++; b->pass_launches[1]++;
+                rest2 = rest & ~SSE_DO_RVB;
+            }
+            if (rest2 || sample) {
                 SweepArgs a2 = A;
-                a2.domask = rest; a2.nsteps = 1; a2.step0 = done;
+                a2.domask = rest2; a2.nsteps = 1; a2.step0 = done;
+                if (rest2 != rest) { // behind an RVB launch: the plain off-diagonal kernel and geometry
+                    LaunchCfg lo = lc;
+                    lo.passes = SSE_PASSES_OFFDIAG;
+                    const LdsPlan po = plan_lds(b, lc.W);
+                    DevBatch dv = use_dev_off ? dev_off : b->dev;
+                    lo.lds_bytes = po.lds_bytes; dv.lds_ufcap = po.ufcap; dv.lds_words = (uint32_t)(po.lds_bytes / 4);
+                    e = launch_dev(lo, dv, a2);
+                } else
                 e = launch_dev(lc, (use_dev_off || lc.passes == SSE_PASSES_OFFDIAG) ? dev_off : b->dev, a2);
                 if (e != hipSuccess) return fail_launch(e);
                 launches++; b->pass_launches[1]++;
@@ -1033,6 +1078,19 @@ int isingmc_get_bond_count(isingmc_batch *b, uint32_t r, uint32_t bond, uint32_t
     return ISINGMC_OK;
 }
 
+int isingmc_debug_counts(isingmc_batch *b, uint32_t *out) {
+    if (!b || !out) return ISINGMC_EINVAL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    uint32_t *d = nullptr;
+    HIP_TRY(b, hipMalloc((void **)&d, 12 * (size_t)b->dev.R));
+    hipLaunchKernelGGL(debug_counts_kernel, dim3(b->dev.R), dim3(256), 0, b->stream, b->dev, d);
+    hipError_t e = hipMemcpyAsync(out, d, 12 * (size_t)b->dev.R, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { b->err = std::string("debug_counts: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; }
+    return ISINGMC_OK;
+}
+
 int isingmc_verify(isingmc_batch *b, uint8_t *ok) {
     if (!b || !ok) return ISINGMC_EINVAL;
     HIP_TRY(b, hipSetDevice(b->device));
@@ -1303,6 +1361,34 @@ int isingmc_pt_get_slots(isingmc_batch *b, uint32_t *slot_of_replica, double *be
         if (beta_of_replica) beta_of_replica[r] = P->betas[P->slot_of[r] / P->nchains];
         if (config_id_of_replica) config_id_of_replica[r] = P->rid[r];
     }
+    return ISINGMC_OK;
+}
+
+// Container-level save / load (the reference serialises the whole TemperingContainer, tempering_container.rs:683-792): the labels,
+// the configurations' identities and the step counter; the replicas themselves go through the batch's own checkpoint.
+int isingmc_pt_get_state(isingmc_batch *b, uint64_t *step, uint64_t *total_swaps) {
+    if (!b || !b->pt) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    if (step) *step = b->pt->step;
+    if (total_swaps) *total_swaps = b->pt->total_swaps;
+    return ISINGMC_OK;
+}
+int isingmc_pt_set_state(isingmc_batch *b, const uint32_t *slot_of_replica, const uint32_t *config_id_of_replica, uint64_t step, uint64_t total_swaps) {
+    if (!b || !b->pt || !slot_of_replica || !config_id_of_replica) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    PtState *P = b->pt;
+    const uint32_t R = b->dev.R, lo = P->rank * R;
+    std::vector<uint8_t> seen(R, 0);
+    for (uint32_t r = 0; r < R; ++r) {
+        if (slot_of_replica[r] < lo || slot_of_replica[r] >= lo + R || seen[slot_of_replica[r] - lo]) { b->err = "slots must be a permutation of this rank's temperature block"; return ISINGMC_EINVAL; }
+        seen[slot_of_replica[r] - lo] = 1;
+    }
+    HIP_TRY(b, hipSetDevice(b->device));
+    for (uint32_t r = 0; r < R; ++r) { P->slot_of[r] = slot_of_replica[r]; P->rid[r] = config_id_of_replica[r]; }
+    HIP_TRY(b, hipMemcpy(P->d_rid, P->rid.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
+    if (P->hams_differ) {
+        for (uint32_t r = 0; r < R; ++r) b->ham_row_host[r] = P->slot_of[r] - lo;
+        HIP_TRY(b, hipMemcpy(P->d_ham_row, b->ham_row_host.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
+    }
+    P->step = step; P->total_swaps = total_swaps;
     return ISINGMC_OK;
 }
 

@@ -1459,7 +1459,7 @@ namespace sse {
 #ifndef SSE_MIN_WAVES_PER_SIMD
 #define SSE_MIN_WAVES_PER_SIMD 1
 #endif
-enum { SSE_PASSES_ALL = 0, SSE_PASSES_DIAG = 1, SSE_PASSES_OFFDIAG = 2 }; // DIAG: diagonal pass + directed loop; OFFDIAG: cluster + free spins + sampling
+enum { SSE_PASSES_ALL = 0, SSE_PASSES_DIAG = 1, SSE_PASSES_OFFDIAG = 2, SSE_PASSES_RVB = 3 }; // DIAG: diagonal pass + directed loop; OFFDIAG: cluster + free spins + sampling; RVB: the RVB sweep alone (its own register budget)
 template <int W, int PASSES>
 constexpr int sse_waves_per_simd() {
     if (PASSES == SSE_PASSES_DIAG) return W <= 4 ? 4 : (W <= 8 ? 2 : 1);
@@ -1491,7 +1491,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
     uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0;
     for (uint64_t step = 0; step < A.nsteps; ++step) {
         if (err) break;
-        if constexpr (PASSES != SSE_PASSES_OFFDIAG)
+        if constexpr (PASSES != SSE_PASSES_OFFDIAG && PASSES != SSE_PASSES_RVB)
         if (A.domask & SSE_DO_DIAG) {
             const Rng rng = make_rng(B, r, epoch);
             if (A.domask & SSE_DO_HEATBATH) diagonal_pass<W, K, CL, true, TG>(B, L, r, rng, beta, M, n, ntrans, gr);
@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
                 if (want > M) { if (want > B.cap) { err = 1u; break; } M = want; }
             }
         }
-        if constexpr (PASSES == SSE_PASSES_ALL && !TG) // (RVB keeps its working set in LDS: refused by the host for MODE 2 models)
+        if constexpr ((PASSES == SSE_PASSES_ALL || PASSES == SSE_PASSES_RVB) && !TG) // (RVB keeps its working set in LDS: refused by the host for MODE 2 models)
         if (A.domask & SSE_DO_RVB) { // qmc_ising.rs:705-752
             const uint32_t updates = A.rvb_updates ? A.rvb_updates : (B.N + 1u) / 2u;
             last_out = rvb_pass<W, CL>(B, L, r, epoch, M, updates, gr, err);
@@ -1512,7 +1512,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
             if (err) break;
         }
         // the directed loop is one sequential walk: it runs in the small geometry of the diagonal launch
-        if constexpr (PASSES != SSE_PASSES_OFFDIAG)
+        if constexpr (PASSES != SSE_PASSES_OFFDIAG && PASSES != SSE_PASSES_RVB)
         if (A.domask & SSE_DO_LOOP) {
             const Rng rng = make_rng(B, r, epoch);
             last_out = loop_pass<W, CL>(B, L, r, rng, M, n, gr, err);
@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
             a4 += last_out;
             if (err) break;
         }
-        if constexpr (PASSES != SSE_PASSES_DIAG) {
+        if constexpr (PASSES != SSE_PASSES_DIAG && PASSES != SSE_PASSES_RVB) {
         if (A.domask & SSE_DO_CLUSTER) {
             const Rng rng = make_rng(B, r, epoch);
             const uint32_t S_ids = (uint32_t)W * B.N + (uint32_t)ntrans;
@@ -1603,6 +1603,10 @@ hipError_t launch_k(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
     if (c.passes == SSE_PASSES_OFFDIAG) {
         if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_OFFDIAG>(c, B, A);
         return launch_one<W, K, CL, 0, SSE_PASSES_OFFDIAG>(c, B, A);
+    }
+    if (c.passes == SSE_PASSES_RVB) {
+        if constexpr (CL != SSE_MODE_GLOBAL_TABLES) return launch_one<W, K, CL, 0, SSE_PASSES_RVB>(c, B, A);
+        else return hipErrorInvalidValue;
     }
     if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_ALL>(c, B, A); // data-preparation symbol: default geometry only
     return launch_one<W, K, CL, 0, SSE_PASSES_ALL>(c, B, A);

@@ -285,3 +285,24 @@ class NativeTemperingContainer:
 
     def verify(self):
         return bool(np.all(self.g.verify()))
+
+    # ---- container-level save / load (tempering_container.rs:683-792 serialises the whole container) ----
+    def save(self, path):
+        """This rank's share: the batch checkpoint (`path`.batch.npz) plus labels, configuration identities and step counter."""
+        self.g.save_checkpoint(path + ".batch.npz")
+        step, sw = C.c_uint64(0), C.c_uint64(0)
+        self.g._check(self.g._lib.isingmc_pt_get_state(self.g._h, C.byref(step), C.byref(sw)))
+        np.savez(path + ".pt.npz", slot_of=self.slot_of, config_of=self.config_of, step=np.uint64(step.value), swaps=np.uint64(sw.value),
+                 betas=self.betas, nchains=np.uint32(self.nchains), rank=np.uint32(self.rank), world=np.uint32(self.world),
+                 swaps_local=np.uint64(self.total_swaps_local))
+
+    def load(self, path):
+        z = np.load(path + ".pt.npz", allow_pickle=False)
+        if not np.array_equal(z["betas"], self.betas) or int(z["nchains"]) != self.nchains or int(z["rank"]) != self.rank or int(z["world"]) != self.world:
+            raise RuntimeError("tempering checkpoint belongs to a different layout")
+        self.g.load_checkpoint(path + ".batch.npz")
+        so = np.ascontiguousarray(z["slot_of"].astype(np.uint32)); co = np.ascontiguousarray(z["config_of"].astype(np.uint32))
+        self.g._check(self.g._lib.isingmc_pt_set_state(self.g._h, so.ctypes.data_as(C.POINTER(C.c_uint32)), co.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                        int(z["step"]), int(z["swaps"])))
+        self.total_swaps_local = int(z["swaps_local"])
+        self._refresh()

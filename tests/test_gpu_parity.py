@@ -631,3 +631,44 @@ def test_segment_labelling_on_the_diagonal_kernel(oracle, k, flags):
     for r, rep in enumerate(reps):
         assert np.array_equal(acc[r, :7], rep.accumulators()[:7])
     assert g.verify().all()
+
+
+def test_debug_ops_counters_and_serde_layout(oracle):
+    """DebugOps (qmc_debug.rs:10-41) on the device, and the checkpoint in the reference's serde field layout
+    (qmc_ising.rs:1010-1028 and members) as a round trip through JSON."""
+    import json
+    import isingmontecarlo_amd as im
+    from isingmontecarlo_amd.serde_format import to_serde, from_serde
+    edges = lat.one_d_periodic(6, -1.0)
+    R = 3
+    g, m, reps = make_pair(oracle, edges, 0.9, 0.3, 6, 1 << 11, 99, R)
+    g.run(40, 2.0)
+    oracle.batch_timesteps(reps, 40, [2.0] * R)
+    d, o = g.count_diagonal_and_off()
+    c = g.count_constant_ops()
+    n = g.get_n()
+    for r, rep in enumerate(reps):
+        w = rep.ops()
+        occ = w[w != 0]
+        nd = int(((occ & 3) == ((occ >> 2) & 3)).sum())
+        bond = (occ >> 4).astype(np.int64) - 1
+        assert (int(d[r]), int(o[r])) == (nd, len(occ) - nd) and int(d[r]) + int(o[r]) == n[r]
+        assert int(c[r]) == int(((bond >= 6) & (bond < 12)).sum())
+    ser = json.loads(json.dumps(to_serde(g, 1)))
+    assert set(ser) == {"edges", "transverse", "longitudinal", "state", "cutoff", "op_manager", "total_energy_offset", "nvars",
+                        "run_rvb_steps", "classical_bonds", "total_rvb_successes", "rvb_clusters_counted", "bond_weights"}
+    man = ser["op_manager"]
+    assert man["n"] == n[1] and sum(man["bond_counters"]) == n[1] and len(man["var_ends"]) == 6
+    first, last = man["p_ends"]
+    assert man["ops"][first]["previous_p"] is None and man["ops"][last]["next_p"] is None
+    p, seen = first, 0
+    while p is not None:  # the p-links visit every op once, in order
+        seen += 1
+        nxt = man["ops"][p]["next_p"]
+        assert nxt is None or nxt > p
+        p = nxt
+    assert seen == n[1]
+    g2 = im.QmcIsingGraph(edges, 0.9, 0.3, 6, 99, nreplicas=1, capacity=1 << 11)
+    from_serde(g2, ser, 0)
+    assert np.array_equal(g2.export_ops(0), g.export_ops(1)) and np.array_equal(g2.state_ref()[0], g.state_ref()[1])
+    assert g2.verify().all()

@@ -138,3 +138,28 @@ def test_relative_weights_between_different_hamiltonians(oracle):
         assert int(tc.config_of[r]) == ids[t]
         assert n[r] == reps[t].n and np.array_equal(st[r], reps[t].state()) and np.array_equal(g.export_ops(r), reps[t].ops())
     assert tc.verify() and all(r.verify() for r in reps)
+
+
+def test_container_save_and_load_resume_bit_exactly(oracle, tmp_path):
+    """Container-level checkpoint (tempering_container.rs:683-792 serialises the whole container): a restored container
+    continues exactly like the one that kept running — swaps, labels, configurations."""
+    import isingmontecarlo_amd as im
+    def make():
+        g = im.QmcIsingGraph(lat.two_d_periodic(4), 1.0, 0.0, 16, SEED, nreplicas=len(BETAS) * K, capacity=4096)
+        return g, im.NativeTemperingContainer(g, BETAS, K, SEED)
+    g1, t1 = make()
+    for _ in range(6):
+        t1.timesteps(SWEEPS); t1.tempering_step()
+    path = str(tmp_path / "ck")
+    t1.save(path)
+    g2, t2 = make()
+    t2.load(path)
+    for tc in (t1, t2):
+        for _ in range(5):
+            tc.timesteps(SWEEPS); tc.tempering_step()
+    assert t1.get_total_swaps() == t2.get_total_swaps() > 0
+    assert np.array_equal(t1.slot_of, t2.slot_of) and np.array_equal(t1.config_of, t2.config_of)
+    assert np.array_equal(g1.get_n(), g2.get_n()) and np.array_equal(g1.state_ref(), g2.state_ref())
+    for r in range(g1.nreplicas):
+        assert np.array_equal(g1.export_ops(r), g2.export_ops(r))
+    assert t2.verify()
