@@ -11,8 +11,12 @@ warm-up (the cutoff must first grow from N to ~1.5 n; that growth is data prepar
 value = spin-operator updates / second, whole job: one update = one op-string slot processed by one pass
 (diagonal pass: cutoff M slots; off-diagonal passes: vertices visited), summed over all ranks' replicas.
 
-Multi-GPU: replicas shard across ranks (weak scaling: 1024 replicas per GPU), no data-path collective;
-launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+Multi-GPU: replicas shard across ranks, no data-path collective; launched by the driver as
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.  BASELINE's metric reads "1024 replicas at 1/2/4/8
+GPUs"; `value` is the WEAK-scaling reading (1024 replicas on every GPU: the per-GPU work that fills the machine — the diagonal
+launch runs 4 workgroups of 4 waves per CU, i.e. exactly 1024 replicas on 256 CUs; fewer replicas per GPU leave CUs idle), and
+for N > 1 the line also carries the STRONG-scaling reading (1024 replicas in total, 1024/N per GPU) under `strong_scaling`,
+measured in the same invocation.
 """
 import argparse
 import json
@@ -81,6 +85,27 @@ def cpu_baseline(l, beta, flags, seed, budget_s=20.0):
             "sample": f"{nthreads} replicas (one per thread) x {sweeps} sweeps of the same {l}x{l} beta={beta} "
                       f"workload after 60 equilibration sweeps; C oracle, not the Rust binary",
             "sweeps_per_s_per_core": sweeps / dt, "host_logical_cpus": os.cpu_count()}
+
+
+METRIC = "spin-op updates/sec (whole node), 32\u00d732 TFIM, 1024 replicas at 1/2/4/8 GPUs"  # BASELINE.json, verbatim
+
+
+def timed_run(g, steps, warmup, beta, flags, dist, torch):
+    """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides; returns seconds."""
+    if warmup:
+        g.run(warmup, beta, flags=flags)
+    g.reset_accumulators()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.run(steps, beta, flags=flags)  # EXACTLY K steps, returns after completion
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -160,21 +185,9 @@ def main():
     # Two kernel launches per sweep (isingmc_hip.hip run()): diagonal pass + directed loop (sse::sweep_kernel<..,PASSES=1>)
     # and cluster + free spins (sse::sweep_kernel<..,PASSES=2>).  A "launch" in the
     # roofline object is one launch of the dominant kernel = its pass over all R replicas of this rank.
-    if args.warmup:
-        g.run(args.warmup, beta, flags=flags)
-    g.reset_accumulators()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    g.run(args.steps, beta, flags=flags)  # EXACTLY K steps = K diagonal + K off-diagonal launches, returns after completion
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = timed_run(g, args.steps, args.warmup, beta, flags, dist, torch)
 
+    pass_ms = g.last_pass_ms()
     acc = g.accumulators().astype(np.float64)
     updates = float(acc[:, 4].sum() + acc[:, 5].sum())
     slots = float(acc[:, 5].sum())  # sum over replicas and steps of the cutoff M
@@ -190,17 +203,38 @@ def main():
         dt, updates, slots_all = float(tmax[0]), float(tsum[1]), float(tsum[2])
     else:
         slots_all = slots
+    launch_info = g.launch_info()
+    energy = -(acc[:, 0] / np.maximum(acc[:, 1], 1)) / beta + g.get_offsets()
+    # ---- strong-scaling reading of the same metric (N > 1): 1024 replicas in total, R/N per GPU ----
+    strong = None
+    if world > 1 and not args.pmj3d and not args.rvb and R % world == 0:
+        del g
+        Rs = R // world
+        gs = im.QmcIsingGraph(edges, 1.0, 0.0, L * L, args.seed, nreplicas=Rs, capacity=cap, replica_offset=rank * Rs,
+                              device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k)
+        for _ in range(0, args.equilibrate, 10):
+            gs.run(min(10, args.equilibrate), beta, flags=flags | im.FLAG_PREP)
+        dts = timed_run(gs, args.steps, args.warmup, beta, flags, dist, torch)
+        accs = gs.accumulators().astype(np.float64)
+        ts = torch.tensor([dts, float(accs[:, 4].sum() + accs[:, 5].sum())], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tm = ts.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        tsu = ts.clone(); dist.all_reduce(tsu, op=dist.ReduceOp.SUM)
+        strong = {"scaling": "strong", "replicas_total": R, "replicas_per_gpu": Rs, "value": float(tsu[1]) / float(tm[0]),
+                  "ms_per_step": float(tm[0]) * 1e3 / args.steps,
+                  "note": "1024/N replicas per GPU leave (N-1)/N of the diagonal launch's workgroup slots empty"}
 
     if rank == 0:
         # per kernel: algorithmic bytes per launch / average launch duration (HIP events recorded around every
         # launch on the launch stream by the library, isingmc_last_pass_ms)
-        (ms_diag, ms_rest), (l_diag, l_rest) = g.last_pass_ms()
+        (ms_diag, ms_rest), (l_diag, l_rest) = pass_ms
         b_rest = BYTES_PER_SLOT_CLUSTER
         if args.rvb:
             b_rest += 8.0  # find_constants reads the op-string twice (count + fill); window traffic not counted
         kernels = []
-        for name, bps, ms, nl in (("sse::sweep_kernel<W,K,CL,0,PASSES=1> (diagonal pass + directed loop)", BYTES_PER_SLOT_DIAG, ms_diag, l_diag),
-                                  ("sse::sweep_kernel<W,K,CL,0,PASSES=%d> (%scluster + free spins)" % ((0, "RVB sweep + directed loop + ") if args.rvb else (2, "")), b_rest, ms_rest, l_rest)):
+        diag_name = ("sse::sweep_fast_kernel<K,0,LABEL> (diagonal pass + directed loop)" if launch_info.get("fast_diagonal") and not (flags & im.FLAG_HEATBATH)
+                     else "sse::sweep_kernel<W,K,CL,0,PASSES=1> (diagonal pass + directed loop)")
+        for name, bps, ms, nl in ((diag_name, BYTES_PER_SLOT_DIAG, ms_diag, l_diag),
+                                  ("sse::sweep_kernel<W,K,CL,0,PASSES=%s> (%scluster + free spins)" % (("3 then 2", "RVB sweep, then ") if args.rvb else ("2", "")), b_rest, ms_rest, l_rest)):
             if nl == 0:
                 continue
             per_launch_bytes = bps * slots / args.steps
@@ -214,17 +248,16 @@ def main():
             # HBM bytes per launch of the dominant kernel from the PMC passes of this same workload (cannot be
             # collected inside this process: rocprofv3 counters need their own runs), see profiles/README.md
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                    traffic = float(json.load(f)["PASSES=2" if "PASSES=0" in dom["kernel"] or "PASSES=2" in dom["kernel"] else "PASSES=1"])
+                with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+                    traffic = float(json.load(f)["offdiagonal" if "PASSES=2" in dom["kernel"] else "diagonal"])
             except (OSError, KeyError, ValueError):
                 traffic = None
         achieved = dom["achieved_GBps"]
         bytes_per_sweep = sum(k["algorithmic_bytes_per_launch"] for k in kernels)
         sweep_ms = kernel_ms / args.steps
-        energy = -(acc[:, 0] / np.maximum(acc[:, 1], 1)) / beta + g.get_offsets()
         nsites = (args.pmj3d ** 3) if args.pmj3d else L * L
         out = {
-            "metric": "spin-op updates/sec (whole node), 32x32 TFIM, 1024 replicas per GPU",
+            "metric": METRIC,
             "value": updates / dt,
             "unit": "spin-op updates/s",
             "n_gpus": world,
@@ -244,9 +277,11 @@ def main():
                        "mean_cutoff_M": mean_M, "mean_n": mean_n, "sweeps_per_s": args.steps / dt,
                        "updates_diagonal_per_s_rank0": slots / dt,  # U_diag: slots visited by the diagonal pass
                        "updates_offdiagonal_per_s_rank0": float(acc[:, 4].sum()) / dt,  # U_off: cluster + loop vertices
-                       "waves_per_replica": g.launch_info()["waves_per_replica"],
-                       "slots_per_lane": g.launch_info()["slots_per_lane"],
-                       "lds_bytes_per_workgroup": g.launch_info()["lds_bytes"],
+                       "waves_per_replica": launch_info["waves_per_replica"], "waves_per_replica_offdiagonal": launch_info["waves_offdiag"],
+                       "slots_per_lane": launch_info["slots_per_lane"],
+                       "lds_bytes_per_workgroup": launch_info["lds_bytes"],
+                       "tables": "HBM/L2 (per-variable tables exceed LDS)" if launch_info.get("global_tables") else "LDS",
+                       "min_replicas_per_gpu_to_fill_the_chip": 1024,
                        "energy_per_site": float(energy.mean() / nsites),
                        "energy_per_site_sem": float(energy.std(ddof=1) / np.sqrt(R) / nsites) if R > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -257,8 +292,10 @@ def main():
                          "whole_sweep": {"algorithmic_bytes": bytes_per_sweep, "ms": sweep_ms,
                                          "achieved_GBps": bytes_per_sweep / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, beta, flags, args.seed)
+        if strong is not None:
+            out["strong_scaling"] = strong
+        if world == 1 and not args.no_cpu_baseline and not args.pmj3d:
+            out["cpu_baseline"] = cpu_baseline(L, beta, flags, args.seed, budget_s=25.0 if args.rvb else 20.0)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

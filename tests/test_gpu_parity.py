@@ -672,3 +672,18 @@ def test_debug_ops_counters_and_serde_layout(oracle):
     from_serde(g2, ser, 0)
     assert np.array_equal(g2.export_ops(0), g.export_ops(1)) and np.array_equal(g2.state_ref()[0], g.state_ref()[1])
     assert g2.verify().all()
+
+
+def test_64x64_cold_end_runs_on_the_hbm_union_find_and_matches(oracle):
+    """configs[3]'s cold end: 64x64 at beta = 16.  N + (transverse ops) exceeds both the LDS union-find and 16-bit ids
+    (~85,000 cuts), so every sweep takes the 32-bit HBM union-find; ~5e5 slots per replica."""
+    edges = lat.two_d_ferro(64)
+    R = 2
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 4096, 1 << 20, 6416, R)
+    g.run(26, 16.0)
+    oracle.batch_timesteps(reps, 26, [16.0] * R)
+    assert_same(g, reps, "64x64 beta=16")
+    assert g.verify().all()
+    bonds = (reps[0].ops() >> 4).astype(np.int64) - 1
+    ntrans = int(((bonds >= len(edges)) & (bonds < len(edges) + g.nvars)).sum())
+    assert g.nvars + ntrans > 65535 and reps[0].cutoff > 300000

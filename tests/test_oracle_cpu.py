@@ -181,7 +181,7 @@ def test_rvb_hand_built_opstrings_stay_valid():
     tb = lambda v: 1 + v
     strings = [
         [O.op_make(tb(0), 0, 0), O.op_make(tb(0), 0, 1), O.op_make(0, 1, 1), O.op_make(tb(1), 0, 0), O.op_make(tb(0), 1, 0)],
-        [O.op_make(0, 2, 2), 0, O.op_make(tb(1), 1, 0), O.op_make(0, 0, 0)[0:0] if False else 0, O.op_make(tb(1), 0, 1)],
+        [O.op_make(0, 2, 2), 0, O.op_make(tb(1), 1, 0), 0, O.op_make(tb(1), 0, 1)],
         [O.op_make(tb(0), 0, 0)] * 3 + [O.op_make(tb(1), 0, 0)] * 3,
     ]
     states = [[0, 0], [0, 1], [0, 0]]
@@ -260,3 +260,28 @@ def test_generic_interactions_with_cluster_edges_match_exact_diagonalisation(ora
     assert all(rep.verify() for rep in reps)
     sem = es.std(ddof=1) / np.sqrt(R)
     assert abs(es.mean() - exact) < 5 * sem + 5e-3, (es.mean(), sem, exact)
+
+
+def test_oracle_is_clean_under_asan_ubsan(tmp_path):
+    """The oracle's C sources under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build; GPU sanitizers are not available
+    on this pool): every pass, incl. RVB and the tempering step, on small models (oracle/sanitize_main.c)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "ora_san")
+    src = [os.path.join(root, "oracle", f) for f in ("sanitize_main.c", "sse_oracle.c", "sse_oracle_batch.c", "sse_oracle_rvb.c")]
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", "-fopenmp", "-o", exe] + src + ["-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0 and "clean" in out.stdout, out.stdout + out.stderr
+
+
+def test_cpp_example_host_side_builds_with_sanitizers(tmp_path):
+    """examples/small_qmc.cpp (the compiled-code caller of include/isingmc_hip.h) compiles and links against the library with
+    -fsanitize=address,undefined; it needs a GPU to run, which the gpu-marked test does without sanitizers."""
+    import subprocess
+    import isingmontecarlo_amd as im
+    root = os.path.dirname(HERE)
+    libdir = os.path.dirname(im.load_library()._name)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-fsanitize=address,undefined", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "small_qmc.cpp"), "-L" + libdir, "-lisingmc_hip", "-Wl,-rpath," + libdir,
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", str(tmp_path / "small_qmc_san")])
