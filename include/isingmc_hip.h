@@ -56,6 +56,9 @@ extern "C" {
 #define ISINGMC_CFG_FAST_LABEL 32u /* experimental: the trimmed diagonal kernel also labels the worldline segments and hands them to the
                                       cluster update of the same timestep, which then only runs the union-find (same results; on MI355X the
                                       diagonal launch loses more than the cluster update gains, see DESIGN.md, so it is off by default) */
+#define ISINGMC_CFG_COMPACT 64u /* experimental: the trimmed diagonal kernel also writes the occupied slots as a dense list and the cluster
+                                   update of the same timestep scans that list (n instead of M elements; same results; on MI355X the two
+                                   launches trade 0.1 ms for 0.1 ms, see DESIGN.md, so it is off by default) */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 
@@ -262,7 +265,7 @@ int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
  * out[2]=union-find ids that fit in LDS, out[3]=state words per replica, out[4]=slots per lane,
  * out[5]=1 if the edge table is staged in LDS, out[6]=bit 0: timesteps are issued as two launches (diagonal, rest); bit 1: per-variable
  * tables live in HBM (ISINGMC_CFG_GLOBAL_TABLES path); bit 2: the diagonal-pass launch is the trimmed kernel of sse_fast.hip.h; bit 3: ... and it labels the segments for the cluster
- * update of the same timestep; bits 8-15: waves per replica of the
+ * update of the same timestep; bit 4: ... or hands it the dense list of occupied slots; bits 8-15: waves per replica of the
  * most recent off-diagonal launch,
  * out[7]=dynamic LDS bytes of the diagonal-pass launch */
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]);

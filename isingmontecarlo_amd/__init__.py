@@ -14,7 +14,7 @@ from . import _build
 
 __all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "NativeTemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
            "interaction_at", "interaction_sym_under_ising",
-           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J", "CFG_GLOBAL_TABLES", "CFG_NO_FAST_DIAG", "CFG_FAST_LABEL"]
+           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J", "CFG_GLOBAL_TABLES", "CFG_NO_FAST_DIAG", "CFG_FAST_LABEL", "CFG_COMPACT"]
 
 FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
 FLAG_PREP = 0x10000
@@ -23,6 +23,7 @@ CFG_PER_REPLICA_J = 4  # J is [nreplicas][nedges]: one disorder realisation per 
 CFG_GLOBAL_TABLES = 8  # per-variable scan tables in HBM instead of LDS (automatic for large models; forced by this flag)
 CFG_NO_FAST_DIAG = 16  # general diagonal kernel even where the trimmed one applies (testing / A-B timing)
 CFG_FAST_LABEL = 32  # experimental: segment labelling rides on the trimmed diagonal kernel (same results, currently slower)
+CFG_COMPACT = 64  # experimental: cluster update scans the dense op list written by the trimmed diagonal kernel (same results, no net gain yet)
 CFG_FUSED_LAUNCH = 2  # whole timesteps in one kernel launch (default: diagonal launch + off-diagonal launch)
 ALL = 0xFFFFFFFF
 
@@ -539,7 +540,7 @@ class QmcIsingGraph:
         out = (C.c_uint32 * 8)()
         self._check(self._lib.isingmc_get_launch_info(self._h, out))
         return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3],
-                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), global_tables=bool(out[6] & 2), fast_diagonal=bool(out[6] & 4), fast_label=bool(out[6] & 8),
+                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), global_tables=bool(out[6] & 2), fast_diagonal=bool(out[6] & 4), fast_label=bool(out[6] & 8), compact_list=bool(out[6] & 16),
                     waves_offdiag=(out[6] >> 8) & 0xFF,
                     lds_bytes_diagonal=out[7])
 

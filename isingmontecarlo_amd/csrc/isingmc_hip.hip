@@ -32,7 +32,8 @@ struct isingmc_batch {
     uint32_t last_launches = 0;
     bool fast_diag = false;             // the diagonal-pass launch uses sse_fast.hip.h (headline geometry: LDS edge tables, 4 waves, N <= 4096)
     size_t lds_bytes_fast = 0, lds_bytes_fast_label = 0;
-    bool lite = false;                  // ... and it labels the segments for the cluster update that follows in the same timestep
+    bool compact = false;               // ... and it writes the dense op list for the cluster update that follows in the same timestep
+    bool lite = false;                  // ... or (experimental) labels the segments for the cluster update that follows in the same timestep
     bool fused_launch = false;          // ISINGMC_CFG_FUSED_LAUNCH: whole timesteps in one kernel (no diagonal-only launches)
     std::vector<hipEvent_t> evpool;     // per-launch events of the split path (bounded, see run())
     float pass_ms[2] = {0.f, 0.f};      // [0] diagonal-only launches, [1] all other launches of the last run
@@ -405,6 +406,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         // the cluster update of the same timestep takes the segment labelling from the diagonal launch (nothing but the
         // directed loop may sit in between: it changes no op's position or bond)
         const bool use_label = use_fast && b->lite && (A.domask & SSE_DO_CLUSTER) && !(A.domask & SSE_DO_RVB);
+        const bool use_compact = use_fast && !use_label && b->compact && (A.domask & SSE_DO_CLUSTER) && !(A.domask & SSE_DO_RVB);
         // the diagonal launch needs the fixed regions up to the per-wave tables, which it uses as [W][N] bytes
         ld.lds_bytes = use_fast ? (use_label ? b->lds_bytes_fast_label : b->lds_bytes_fast) : diag_lds_bytes(b);
         const uint32_t rest = A.domask & ~diag_bits;
@@ -420,7 +422,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             }
             const bool timed = done < MAX_TIMED;
             SweepArgs a1 = A;
-            a1.domask = (A.domask & diag_bits) | (use_label ? SSE_DO_LABEL : 0u); a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
+            a1.domask = (A.domask & diag_bits) | (use_label ? SSE_DO_LABEL : 0u) | (use_compact ? SSE_DO_COMPACT : 0u); a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
             if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done], b->stream));
             hipError_t e = use_fast ? launch_sweep_fast(ld, b->dev, a1) : launch(ld, a1);
             if (e != hipSuccess) return fail_launch(e);
@@ -681,6 +683,8 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
                    !(cfg->flags & ISINGMC_CFG_NO_FAST_DIAG) && b->lds_bytes_fast <= 40 * 1024; // 4 workgroups per CU
     // ... and labels the segments for the cluster update of the same timestep (h = 0: no frozen segments to track)
     b->lds_bytes_fast_label = fast_lds_bytes(D.N, D.nwords, D.E, D.Nb, true);
+    // (opt-in as well: the diagonal launch pays for the two extra stores per op what the shorter scan gains)
+    b->compact = b->fast_diag && (cfg->flags & ISINGMC_CFG_COMPACT) && !(cfg->flags & ISINGMC_CFG_FAST_LABEL);
     // (opt-in: measured on MI355X the labelling costs the diagonal launch more than it saves the cluster update)
     b->lite = b->fast_diag && !has_long && (cfg->flags & ISINGMC_CFG_FAST_LABEL) && b->lds_bytes_fast_label <= 40 * 1024;
     { // the RVB pass reuses everything from the scan tables on: launches that run it get enough LDS for its scratch
@@ -757,6 +761,12 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     }
     const size_t ufstride = ids_max + 2 * ((ids_max + 31) / 32);
     if ((rc = dalloc(b, &D.uf_scratch, (size_t)D.R * ufstride, false))) return fail(rc);
+    if (b->compact) {
+        if ((rc = dalloc(b, &D.cops, (size_t)D.R * D.stride, false))) return fail(rc);
+        if ((rc = dalloc(b, &D.cpos, (size_t)D.R * D.stride, false))) return fail(rc);
+        if ((rc = dalloc(b, &D.cops_epoch, D.R, false))) return fail(rc);
+        if (hipMemset(D.cops_epoch, 0xFF, sizeof(uint64_t) * D.R) != hipSuccess) { b->err = "hipMemset failed"; return fail(ISINGMC_ENODEVICE); }
+    }
     if (b->lite) {
         D.lite = 1u;
         if ((rc = dalloc(b, &D.pairs, (size_t)D.R * D.stride, false))) return fail(rc);
@@ -1140,7 +1150,7 @@ int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u) | (b->lite ? 8u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
+    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u) | (b->lite ? 8u : 0u) | (b->compact ? 16u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
     return ISINGMC_OK;
 }
 
@@ -1219,6 +1229,7 @@ __global__ void pt_unpack_kernel(DevBatch B, uint32_t *rid, const uint32_t *item
         B.n[r] = o[0]; B.ntrans[r] = o[1]; B.cutoff[r] = o[2]; B.err[r] = o[3];
         B.epoch[r] = (uint64_t)o[4] | ((uint64_t)o[5] << 32); rid[r] = o[6];
         if (B.lite) B.lite_epoch[r] = ~0ull;
+        if (B.cops) B.cops_epoch[r] = ~0ull;
     }
     for (uint32_t i = threadIdx.x; i < B.nwords; i += blockDim.x) B.state[(size_t)r * B.nwords + i] = o[PT_HDR + i];
     for (uint32_t i = threadIdx.x; i < 2 * SSE_MAX_CHUNKS; i += blockDim.x) B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i] = o[PT_HDR + B.nwords + i];

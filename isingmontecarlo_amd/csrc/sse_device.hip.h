@@ -67,6 +67,9 @@ struct DevBatch {
     uint32_t *touchbits;  // [R][nwords] variables that carry an op
     uint64_t *lite_epoch; // [R] the update counter at which segs / pairs describe the op-string (any other primitive in between
                           // moves the counter on and the cluster update falls back to its own scan)
+    // ... or, instead, the dense list of the occupied slots in p order (the cluster update scans n instead of M elements)
+    uint32_t *cops, *cpos; // [R][stride] op words / their slots; null = not allocated
+    uint64_t *cops_epoch;  // [R] the update counter at which the list describes the op-string
     uint8_t *tbl;         // [R][tbl_stride] per-variable tables in HBM/L2 for models whose tables exceed LDS (MODE 2, see Tab)
     uint32_t tbl_stride;  // bytes per replica: Wmax*N*2 (cut ranks / spin bytes) + Wmax*N (cut markers) + N (touched), rounded up to 16
     uint32_t seed_lo, seed_hi, replica_offset;
@@ -101,6 +104,7 @@ struct DevBatch {
 #define SSE_DO_GROW 16u
 #define SSE_DO_HEATBATH 32u
 #define SSE_DO_RVB 64u
+#define SSE_DO_COMPACT 256u // trimmed diagonal launch only: write the dense op list for the cluster update of the same timestep
 #define SSE_DO_LABEL 128u // trimmed diagonal launch only: label the segments for the cluster update of the same timestep
 
 struct SweepArgs {
@@ -831,9 +835,14 @@ __device__ __forceinline__ void uf_union_wave(const UFA<false> &uf, uint32_t a, 
 //   [N+C, N+C+(W-1)N)     P(w,v): "whatever segment v is in when wave w's range begins" — artificial ids, larger
 //                                 than every real id so they are never roots; joined to the real segments after
 //                                 the scan (cluster_pass).
-template <int W, int K, bool CL, bool APPLY, bool G, bool TG>
+// COMPACT: the scan reads the dense list of occupied slots that the trimmed diagonal kernel of this timestep wrote (B.cops /
+// B.cpos) instead of the padded op-string: the same p-ordered stream without its empty slots (a third of all slots at
+// M = 1.5 n), every lane of every row useful.  Ranges are still bounded by chunks of the padded string — their occupied counts
+// (o_chn) give the corresponding ranges of the list — and the segment ids still land at the ops' slots (segs[cpos]).
+template <int W, int K, bool CL, bool APPLY, bool G, bool TG, bool COMPACT = false>
 __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<G> &uf,
                                              uint32_t C) {
+    static_assert(!COMPACT || (!APPLY && !G && !TG), "the dense list feeds the build scan of the LDS union-find path");
     constexpr int NT = W * 64;
     const Tab<TG> T = make_tab<TG, W>(B, L, r);
     constexpr uint32_t TS = 64 * K; // slots per wave-tile
@@ -853,24 +862,33 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
     for (uint32_t c = lane; c < c0; c += 64) cutbase += LDSW(L.o_chtr, c);
     for (int off = 32; off > 0; off >>= 1) cutbase += __shfl_xor(cutbase, off);
     cutbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cutbase);
-    const uint32_t pbeg = c0 * B.CH, pend = min(c1 * B.CH, M);
+    uint32_t pbeg = c0 * B.CH, pend = min(c1 * B.CH, M);
+    const uint32_t *src = ops;                      // the stream this wave scans: the padded string, or the dense list
+    const uint32_t *cpos = nullptr;
+    if constexpr (COMPACT) {
+        uint32_t nb = 0, ne = 0;                    // ops in front of the range / up to its end
+        for (uint32_t c = lane; c < c1; c += 64) { const uint32_t x = LDSW(L.o_chn, c); ne += x; nb += c < c0 ? x : 0u; }
+        for (int off = 32; off > 0; off >>= 1) { nb += __shfl_xor(nb, off); ne += __shfl_xor(ne, off); }
+        pbeg = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb); pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)ne);
+        src = B.cops + (size_t)r * B.stride; cpos = B.cpos + (size_t)r * B.stride;
+    }
     const uint32_t my_placeholder_base = wave == 0 ? 0u : N + C + (uint32_t)(wave - 1) * N;
     const uint32_t idbase = N + cutbase - 1u; // id of the cut with local rank+1 == x is idbase + x
     if (lane == 0) LDSW(L.o_chg, wave) = idbase; // read back by cluster_pass when it joins the ranges
     uint32_t nlocal = 0;                      // cuts seen so far in this wave's range
     // branch-free prefetch (see diagonal_pass): ranges are whole tiles except at the end of the string, where the
     // padded row holds zeros; past the range end the last tile is simply read again
-    uint32_t wnext[K];
+    uint32_t wnext[K], posn[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, pbeg + j * 64 + lane);
+    for (int j = 0; j < K; ++j) { wnext[j] = row_ld(src, pbeg + j * 64 + lane); if constexpr (COMPACT) posn[j] = row_ld(cpos, pbeg + j * 64 + lane); }
     for (uint32_t p0 = pbeg; p0 < pend; p0 += TS) {
-        uint32_t word[K];
+        uint32_t word[K], pos[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) word[j] = (p0 + j * 64 + lane < pend) ? wnext[j] : 0u;
+        for (int j = 0; j < K; ++j) { word[j] = (p0 + j * 64 + lane < pend) ? wnext[j] : 0u; pos[j] = COMPACT ? posn[j] : p0 + j * 64 + lane; }
         {
             const uint32_t pn0 = p0 + TS < pend ? p0 + TS : p0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, pn0 + j * 64 + lane);
+            for (int j = 0; j < K; ++j) { wnext[j] = row_ld(src, pn0 + j * 64 + lane); if constexpr (COMPACT) posn[j] = row_ld(cpos, pn0 + j * 64 + lane); }
         }
         uint32_t ua[K], uc[K]; // the tile's unions, issued together after the K sub-rounds (unions commute)
         bool utwo[K];
@@ -945,7 +963,8 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                 if (B.has_long) if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
                 if constexpr (!G) { // ids fit 16 bits on this path: remember them for the apply pass
                     const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
-                    row_st(segs_row, p0 + j * 64 + lane, seg_a | (hi << 16));
+                    if constexpr (COMPACT) { if (nonempty) row_st(segs_row, pos[j], seg_a | (hi << 16)); } // (lanes past the range end hold no slot)
+                    else row_st(segs_row, pos[j], seg_a | (hi << 16));
                 }
             } else {
                 const uint32_t fa = uf.get(seg_a), fc = uf.get(seg_c), fo = uf.get(iscut ? id_own : seg_a);
@@ -1052,7 +1071,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
 
 // Cluster update.  Reference: ClusterUpdater::flip_each_cluster_rng (qmc_traits/cluster.rs:36-172) with the
 // longitudinal weight function of qmc_ising.rs:759-775.  Returns the number of clusters.
-template <int W, int K, bool CL, bool UF_GLOBAL, bool TG, bool LITE = false>
+template <int W, int K, bool CL, bool UF_GLOBAL, bool TG, bool LITE = false, bool COMPACT = false>
 __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double prob,
                                                  uint32_t M, int n, int ntrans, uint32_t &gr, uint32_t &err) {
     static_assert(UF_GLOBAL || !TG, "tables in HBM imply the HBM union-find");
@@ -1118,7 +1137,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     __syncthreads();
     // ---- build: label legs with segment ids, union through non-boundary ops ----
     SSE_STAMP(0);
-    cluster_scan<W, K, CL, false, UF_GLOBAL, TG>(B, L, r, M, uf, C);
+    cluster_scan<W, K, CL, false, UF_GLOBAL, TG, COMPACT>(B, L, r, M, uf, C);
     // touched bytes -> bits (read by the coins, the p=0 state update and the free-spin pass, all behind later barriers)
     for (uint32_t i = tid; i < nwords; i += NT) {
         uint32_t bits = 0;
@@ -1530,6 +1549,13 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
                 const uint32_t S_lite = B.N + (uint32_t)ntrans;
                 if (B.lite && B.lite_epoch[r] == epoch && S_lite <= B.lds_ufcap && S_lite <= 65535u) {
                     last_out = cluster_pass<W, K, CL, false, false, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+                    lite_done = true;
+                }
+            }
+            if constexpr (CL && !TG) {
+                // ... or wrote the dense list of occupied slots for it
+                if (!lite_done && B.cops && B.cops_epoch[r] == epoch && S_ids <= B.lds_ufcap && S_ids <= 65535u) {
+                    last_out = cluster_pass<W, K, CL, false, false, false, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
                     lite_done = true;
                 }
             }

@@ -85,7 +85,12 @@ __device__ __forceinline__ uint32_t fast_entry(const DevBatch &B, uint32_t b, ui
 // slot, the segment pairs joined by two-site ops (B.pairs), touched variables, last cut per worldline.  The labelling of
 // tile t runs one tile late, behind the second barrier of tile t + 1: by then every wave knows how many cuts the earlier
 // waves kept in tile t (dense cut numbering in p order), and has received their cuts in its copy of the rank table.
-template <int K, bool LABEL>
+// COMPACT: also write the occupied slots of the final string as a dense list in p order (B.cops: op words, B.cpos: their
+// slots) for the cluster update of the same timestep, whose ordered scan then runs over n instead of M elements with every lane
+// useful.  An op's index in that list is the number of ops in front of it in the final string: ops in front of the tile (a running
+// total), in the earlier waves' shares of the tile (their old occupancy, published once with the first round of the tile, plus
+// their net accepted moves, which the rounds exchange anyway) and at earlier rows / lanes of this wave (wave masks).
+template <int K, bool LABEL, bool COMPACT>
 __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L, const FastLds &F, uint32_t r, const Rng &rng, double beta,
                                               uint32_t M, int &n_io, int &ntrans_io, uint32_t &gr) {
     constexpr int W = 4, NT = W * 64;
@@ -139,6 +144,9 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
     uint32_t cut2[K];         // the tile before: the same | variable << 16 (still owed to the copies of the earlier waves)
 #pragma unroll
     for (int j = 0; j < K; ++j) { entp[j] = 0u; rk1[j] = 0u; cut2[j] = 0u; }
+    uint32_t ccum = 0;        // COMPACT: ops of the final string in front of the current tile
+    uint32_t *const cops_row = COMPACT ? B.cops + (size_t)r * B.stride : nullptr;
+    uint32_t *const cpos_row = COMPACT ? B.cpos + (size_t)r * B.stride : nullptr;
     uint32_t cntp = 0;        // cuts this wave kept in the previous tile
     uint32_t kbase_prev = 0;  // dense index of this wave's first cut in the previous tile
     uint32_t cuts_before = 0; // cuts in all tiles before the previous one
@@ -249,6 +257,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         // everything else is recomputed from the op word with integer arithmetic when needed — the pass is short of scalar
         // registers, and a spilled mask costs a v_readlane per half and use.
         // ---- phase 1, all rows at once (nothing here depends on the spin tables): random numbers, bond, packed table entry
+        uint32_t occ_w = 0; // COMPACT: ops this wave's share of the tile holds before the update
         {
             uint4 rnd = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -257,7 +266,9 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
                 if ((j & 1) == 0) rnd = rng.draw(SSE_TAG_DIAG, pbase + (uint32_t)(j * 64)); // bit 6 of the slot index is clear on even rows
                 const uint32_t r0 = (j & 1) ? rnd.z : rnd.x;
                 rr1[j] = (j & 1) ? rnd.w : rnd.y;
-                bnd[j] = sel64(sse_ballot(wd != 0u), (wd >> 4) - 1u, __umulhi(r0, Nb));
+                const uint64_t occm = sse_ballot(wd != 0u);
+                if constexpr (COMPACT) occ_w += (uint32_t)popc64(occm);
+                bnd[j] = sel64(occm, (wd >> 4) - 1u, __umulhi(r0, Nb));
                 ent[j] = LDSW(F.o_tab, bnd[j]);
             }
         }
@@ -325,7 +336,8 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         int npref[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) npref[j] = n_start;
-        int tot_all = 0;
+        int tot_all = 0, base = 0;
+        uint32_t occbase = 0, occall = 0;
         bool first = true;
         for (;;) {
             int wtot = 0;
@@ -342,7 +354,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
             }
             const int buf = gr & 1;
             // (LABEL: the first round also carries the number of cuts this wave kept in the previous tile, above bit 0)
-            if (lane == 0) { LDSI(L.o_tot, buf * W + wave) = wtot; LDSW(L.o_chg, buf * W + wave) = (changed ? 1u : 0u) | (LABEL && first ? cntp << 1 : 0u); }
+            if (lane == 0) { LDSI(L.o_tot, buf * W + wave) = wtot; LDSW(L.o_chg, buf * W + wave) = (changed ? 1u : 0u) | (LABEL && first ? cntp << 1 : 0u) | (COMPACT && first ? occ_w << 1 : 0u); }
             __syncthreads();
             if (first) {
                 // this tile's off-diagonal ops -> copies of the earlier waves (every reader of this tile is done); the next
@@ -350,7 +362,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
                 propagate(word, m_earlier);
                 if (tile + 1 < ntiles) propagate(wnext, m_later);
             }
-            int base = 0; tot_all = 0; uint32_t anychg = 0, cbase = 0, call = 0;
+            base = 0; tot_all = 0; uint32_t anychg = 0, cbase = 0, call = 0;
 #pragma unroll
             for (int w2 = 0; w2 < W; ++w2) {
                 const int t = __builtin_amdgcn_readfirstlane(LDSI(L.o_tot, buf * W + w2));
@@ -361,6 +373,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
                 if (w2 < wave) cbase += cw >> 1;
                 call += cw >> 1;
             }
+            if constexpr (COMPACT) if (first) { occbase = cbase; occall = call; }
             if constexpr (LABEL) if (first) {
                 // the previous tile's cuts get their dense numbers and go to the copies of the later waves (read behind the next
                 // barrier); the cuts of the tile before that go to the copies of the earlier waves (which are done labelling it)
@@ -393,11 +406,18 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         // ---- commit ----
         int dn = 0, dtr = 0;
         uint32_t fwn[K], cntn = 0u;
+        uint32_t crun = ccum + occbase + (uint32_t)base; // COMPACT: index of this wave's first op of the tile in the dense list
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const uint32_t fw = sel64(acc[j], neww[j], word[j]);
             row_st(ops, pbase + (uint32_t)(j * 64), fw);
             const uint64_t im = acc[j] & insm[j], rm = acc[j] & remm[j];
+            if constexpr (COMPACT) {
+                const uint64_t nemf = (sse_ballot(word[j] != 0u) & ~rm) | im; // the slot holds an op afterwards
+                const uint32_t ci = __builtin_amdgcn_mbcnt_hi((uint32_t)(nemf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nemf, crun));
+                if (fw != 0u) { row_st(cops_row, ci, fw); row_st(cpos_row, ci, pbase + (uint32_t)(j * 64)); }
+                crun += (uint32_t)popc64(nemf);
+            }
             const uint64_t trm = sse_ballot((ent[j] >> 30) == SSE_FAST_CLASS_G); // the bond at stake is a transverse-field bond
             dn += popc64(im) - popc64(rm);
             dtr += popc64(im & trm) - popc64(rm & trm);
@@ -421,6 +441,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
             if (dtr) atomicAdd(&LDSW(L.o_chtr, ch), (uint32_t)dtr);
         }
         n_start += tot_all;
+        if constexpr (COMPACT) ccum += occall + (uint32_t)tot_all;
     }
     if constexpr (LABEL) if (ntiles > 0u) {
         // drain the labelling pipeline: counts of the last tile, its cuts to the later waves, the owed ones to the earlier waves
@@ -473,8 +494,9 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
 
 // One launch = the diagonal sweep (and, if asked for, the directed loop behind it) of every replica: the first of the two
 // launches of a timestep (isingmc_hip.hip run()), for the geometry above.  PHASE only tags the symbol (see sweep_kernel).
-template <int K, int PHASE, bool LABEL>
+template <int K, int PHASE, bool LABEL, bool COMPACT>
 __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArgs A) {
+    static_assert(!(LABEL && COMPACT), "two alternative hand-overs to the cluster update");
     constexpr int W = 4, NT = W * 64;
     Lds<W> L;
     L.carve(B.N, B.nwords, B.lds_ufcap, B.E, B.has_long);
@@ -501,7 +523,7 @@ __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArg
         if (err) break;
         if (A.domask & SSE_DO_DIAG) {
             const Rng rng = make_rng(B, r, epoch);
-            diagonal_fast<K, LABEL>(B, L, F, r, rng, beta, M, n, ntrans, gr);
+            diagonal_fast<K, LABEL, COMPACT>(B, L, F, r, rng, beta, M, n, ntrans, gr);
             epoch++;
             a5 += M;
             if (A.domask & SSE_DO_GROW) { // qmc_ising.rs:786, qmc_runner.rs:197
@@ -531,6 +553,7 @@ __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArg
         acc[4] += a4; acc[5] += a5;
         // the labelling describes the string as the very next update finds it (cluster ids must fit 16 bits)
         if constexpr (LABEL) B.lite_epoch[r] = (!err && A.nsteps == 1 && B.N + (uint32_t)ntrans <= 65535u) ? epoch : ~0ull;
+        if constexpr (COMPACT) B.cops_epoch[r] = (!err && A.nsteps == 1) ? epoch : ~0ull; // the dense list describes the string as the very next update finds it
     }
 }
 

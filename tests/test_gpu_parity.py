@@ -114,14 +114,22 @@ def test_loop_update_matches(oracle, waves, k, cfgf):
     assert g.verify().all()
 
 
-@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (16, 4, 0), (8, 4, 1), (4, 4, 2), (8, 2, 3)])  # cfgf 2 = fused launches
+# cfgf 2 = fused launches; 0 at the default geometry = trimmed diagonal kernel; 16 = general diagonal kernel;
+# experimental hand-overs to the cluster update: 64 = dense op list, 32 = segment labelling
+@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (16, 4, 0), (8, 4, 1), (4, 4, 2), (8, 2, 3), (0, 0, 0), (0, 0, 64), (0, 0, 16), (4, 2, 0), (0, 0, 32)])
 def test_medium_lattice_many_replicas(oracle, waves, k, cfgf):
     edges = lat.two_d_ferro(16)
     R = 16
     g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 256, 1 << 15, 2024, R, waves=waves, k=k, cfg_flags=cfgf)
+    info = g.launch_info()
+    if waves == 0:
+        assert info["fast_diagonal"] == (cfgf != 16) and info["compact_list"] == (cfgf == 64) and info["fast_label"] == (cfgf == 32)
     g.run(30, 4.0)
     oracle.batch_timesteps(reps, 30, [4.0] * R)
     assert_same(g, reps, "16x16")
+    g.run(10, 4.0, flags=1)  # with a directed loop between the diagonal launch and the cluster update
+    oracle.batch_timesteps(reps, 10, [4.0] * R, 1, 1)
+    assert_same(g, reps, "16x16 + loop")
     assert g.verify().all()
 
 

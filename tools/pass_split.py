@@ -10,7 +10,7 @@ import isingmontecarlo_amd as im
 L, R, beta = 32, 1024, 16.0
 cap = 1 << 18
 for name, cf, kw in (("label+lite K=4", im.CFG_FAST_LABEL, {}), ("label+lite K=2", im.CFG_FAST_LABEL, dict(waves_per_replica=4, slots_per_lane=2, waves_offdiag=16)),
-                     ("no label", 0, {}), ("general diag", im.CFG_NO_FAST_DIAG, {})):
+                     ("no label", 0, {}), ("dense list", im.CFG_COMPACT, {}), ("general diag", im.CFG_NO_FAST_DIAG, {})):
     if len(sys.argv) > 1 and sys.argv[1] not in name:
         continue
     g = im.QmcIsingGraph(lat.two_d_ferro(L), 1.0, 0.0, L * L, 1234, nreplicas=R, capacity=cap, cfg_flags=cf, **kw)
