@@ -36,7 +36,8 @@ struct RvbLds { // word offsets into lds_raw
     uint32_t o_sfl;     // [MAXSUB] bit0 cluster_starting_state, bit1 cluster_state, bit2 substate
     uint32_t o_last;    // [MAXSUB] backward-search result (p+1 of the last op before a window)
     uint32_t o_clv, o_clf; // [MAXCL]
-    uint32_t o_tog;     // [2*MAXCL]
+    uint32_t o_tog;     // [2*MAXCL] toggle positions (sorted)
+    uint32_t o_togs;    // [2*MAXCL] sub-variable of each toggle
     uint32_t o_wfrom, o_wuntil; // [MAXWIN]
     uint32_t o_bfk, o_bfv, o_bfw; // flips set: key (= flip index), var, weight (double = 2 words)
     uint32_t o_bnk, o_bnw;        // no-flips set: key (= var), weight
@@ -55,7 +56,7 @@ __device__ __forceinline__ double &ldsd(uint32_t off, uint32_t i) { return reint
 __host__ __device__ inline uint32_t rvb_fixed_words(uint32_t N, uint32_t E) {
     const uint32_t adj = (N < 65535u && E < 65535u) ? (N + 2) / 2 + E : 0u;
     return 1u + 4 * SSE_RVB_SETCAP + 4 * SSE_RVB_BONDCAP + (N + 1) + N + (N + 1) / 2 + adj + 3 * SSE_RVB_MAXSUB +
-           4 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 2 * SSE_RVB_GCAP + 16;
+           6 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 2 * SSE_RVB_GCAP + 16;
 }
 
 template <int W>
@@ -77,6 +78,7 @@ __device__ __forceinline__ void rvb_carve(RvbLds &R, const Lds<W> &L, const DevB
     R.o_clv = base; base += SSE_RVB_MAXCL;
     R.o_clf = base; base += SSE_RVB_MAXCL;
     R.o_tog = base; base += 2 * SSE_RVB_MAXCL;
+    R.o_togs = base; base += 2 * SSE_RVB_MAXCL;
     R.o_wfrom = base; base += SSE_RVB_MAXWIN;
     R.o_wuntil = base; base += SSE_RVB_MAXWIN;
     R.o_bfk = base; base += SSE_RVB_SETCAP;
@@ -158,6 +160,76 @@ struct WSet {
             i++;
         }
         return i < n ? i : n - 1;
+    }
+};
+
+
+// ---- wave-uniform execution -------------------------------------------------------------------------------------
+// The sequential rule of an attempt is run by ONE WAVE whose 64 lanes all hold the same scalars (the compiler keeps them in
+// SGPRs and branches on them with s_cbranch): the lanes differ only inside the searches, where lane i looks at entry i and a
+// ballot gives the answer — a linear search costs one LDS round trip instead of one per entry.  Stores write the same value
+// from every lane (one LDS write).
+__device__ __forceinline__ double readlane_f64(double x, uint32_t l) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// index of `key` among keys[0, n), -1 when absent
+__device__ __forceinline__ int wv_find(uint32_t o_key, uint32_t n, uint32_t key, int lane) {
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool in = i < n;
+        const uint32_t k = LDSW(o_key, in ? i : 0u);
+        const uint64_t m = sse_ballot(in & (k == key));
+        if (m) return (int)base + __ffsll((long long)m) - 1;
+    }
+    return -1;
+}
+// weighted candidate set of the boundary manager, run by a whole wave (same arithmetic, in the same order, as WSet)
+struct WSetW {
+    uint32_t o_key, o_var, o_w; // o_var == 0xFFFFFFFF: the variable is the key
+    uint32_t n;
+    double total;
+    __device__ __forceinline__ bool add(uint32_t key, uint32_t var, double w, int lane) { // BondContainer::insert of (existing weight + w) (rvb.rs:1044-1045)
+        const int i = wv_find(o_key, n, key, lane);
+        if (i >= 0) {
+            const double old = ldsd(o_w, i), neww = old + w;
+            total += neww - old;
+            ldsd(o_w, i) = neww;
+            return true;
+        }
+        if (n >= SSE_RVB_SETCAP) return false;
+        LDSW(o_key, n) = key;
+        if (o_var != 0xFFFFFFFFu) LDSW(o_var, n) = var;
+        const double neww = 0.0 + w;
+        ldsd(o_w, n) = neww;
+        total += neww;
+        n++;
+        return true;
+    }
+    __device__ __forceinline__ void remove_at(uint32_t i) { // swap-remove (bondcontainer.rs:55-72)
+        const uint32_t last = n - 1;
+        const double w = ldsd(o_w, i), wl = ldsd(o_w, last);
+        const uint32_t kl = LDSW(o_key, last), vl = o_var != 0xFFFFFFFFu ? LDSW(o_var, last) : 0u;
+        LDSW(o_key, i) = kl;
+        if (o_var != 0xFFFFFFFFu) LDSW(o_var, i) = vl;
+        ldsd(o_w, i) = wl;
+        n--;
+        total -= w;
+        if (total < 0.0) total = 0.0;
+    }
+    __device__ __forceinline__ uint32_t pick(double u, int lane) const { // bondcontainer.rs:29-45: the running difference is sequential, the weights arrive 64 at a time
+        double p = u * total;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane;
+            const double w = ldsd(o_w, i < n ? i : 0u);
+            const uint32_t cnt = n - base < 64u ? n - base : 64u;
+            for (uint32_t j = 0; j < cnt; ++j) {
+                p -= readlane_f64(w, j);
+                if (p <= 0.0) return base + j;
+            }
+        }
+        return n - 1;
     }
 };
 
@@ -298,6 +370,37 @@ __device__ __forceinline__ void rvb_overlaps(const RvbLds &R, uint32_t p_start, 
         if (!(eq || has_overlap_start || has_start_within)) break;
         f(ip);
     }
+}
+
+
+// find_overlapping_starts by a whole wave: the position lists are sorted, so the first entry >= p_start is a count, and the
+// run of overlapping segments ends at the first step whose test fails.  Calls f(index) for each overlapping segment, in order.
+template <typename F>
+__device__ __forceinline__ void rvb_overlaps_w(const RvbLds &R, uint32_t p_start, uint32_t p_end, uint32_t cutoff, uint32_t fp0, uint32_t Lf, int lane, F f) {
+    uint32_t bin = 0;
+    for (uint32_t base = 0; base < Lf; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const uint32_t x = LDSW(R.o_cps, fp0 + (i < Lf ? i : 0u));
+        bin += (uint32_t)popc64(sse_ballot((i < Lf) & (x < p_start)));
+    }
+    const uint32_t prev = (bin + Lf - 1) % Lf;
+    const uint32_t lowest = LDSW(R.o_cps, fp0 + prev);
+    const uint32_t off_start = (p_start + cutoff - lowest) % cutoff, off_end = (p_end + cutoff - lowest) % cutoff;
+    uint32_t count = Lf;
+    for (uint32_t base = 0; base < Lf; base += 64u) {
+        const uint32_t step = base + (uint32_t)lane;
+        const bool in = step < Lf;
+        const uint32_t ip = (prev + (in ? step : 0u)) % Lf;
+        const uint32_t p = LDSW(R.o_cps, fp0 + ip);
+        const uint32_t next_p = LDSW(R.o_cps, fp0 + (ip + 1) % Lf);
+        const uint32_t check_start = (p + cutoff - lowest) % cutoff, check_end = (next_p + cutoff - lowest) % cutoff;
+        const bool has_overlap_start = check_start < off_start && off_start < check_end;
+        const bool has_start_within = off_start < check_start && check_start < off_end;
+        const bool eq = (p_start == p_end) || (check_start == check_end);
+        const uint64_t stop = sse_ballot(in & !(eq || has_overlap_start || has_start_within));
+        if (stop) { count = base + (uint32_t)__ffsll((long long)stop) - 1u; break; }
+    }
+    for (uint32_t step = 0; step < count; ++step) f((prev + step) % Lf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -491,14 +594,16 @@ __device__ __forceinline__ void rvb_state_at(const DevBatch &B, const Lds<W> &L,
 template <int W, bool CL>
 __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, uint64_t epoch, uint32_t M, uint32_t updates,
                                              uint32_t &gr, uint32_t &err) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t N = B.N;
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     RvbLds R;
     rvb_carve<W>(R, L, B);
     if (tid == 0) LDSW(R.o_ctl, RC_ERR) = 0u;
     __syncthreads();
+    SSE_STAMP_INIT; // diagnostic builds: 6 constants table, 7 growth, 8 states, 9 gathers, 10 replay (probability), 11 accept, 12 replay (mutation)
     const uint32_t C = rvb_find_constants<W, CL>(B, L, R, r, M);
+    SSE_STAMP(6);
     if (C == 0xFFFFFFFFu) { err = 6u; return 0u; } // constant-op table does not fit in LDS
     const uint32_t nzero = LDSW(R.o_ctl, RC_NZERO);
     uint32_t nsucc = 0;
@@ -506,35 +611,44 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
     for (uint32_t attempt = 0; attempt < updates; ++attempt) {
         RvbDraw g;
         g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.rid ? B.rid[r] : B.replica_offset + r; g.epoch_lo = (uint32_t)epoch; g.attempt = attempt; g.k = 0;
-        // ================= phase A (sequential lane): start, cluster growth, sub-variables, windows =================
-        if (tid == 0) {
+        // ================= phase A (one wave, uniform): start, cluster growth, sub-variables, windows =================
+        if (wave == 0) {
             uint32_t lerr = 0;
             uint4 o = g.next();
             const uint32_t choice = __umulhi(o.x, C + nzero);
             uint32_t v0, f0;
-            if (choice < C) {
-                uint32_t lo = 0, hi = N;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (LDSW(R.o_vstart, mid) <= choice) lo = mid; else hi = mid; }
+            if (choice < C) { // the variable whose range of the position table holds `choice`: 64-way search
+                uint32_t lo = 0, hi = N; // vstart[lo] <= choice < vstart[hi]
+                while (hi - lo > 1u) {
+                    const uint32_t step = (hi - lo + 63u) / 64u, idx = lo + (uint32_t)lane * step;
+                    const uint32_t x = LDSW(R.o_vstart, idx < hi ? idx : lo);
+                    const uint32_t cnt = (uint32_t)popc64(sse_ballot((idx < hi) & (x <= choice))); // a prefix of the lanes (lane 0 always)
+                    const uint32_t nhi = lo + cnt * step;
+                    lo += (cnt - 1u) * step;
+                    hi = nhi < hi ? nhi : hi;
+                }
                 v0 = lo; f0 = choice;
             } else { v0 = LDSW(R.o_zero, choice - C); f0 = SSE_NO_VAR; }
             o = g.next();
             unsigned long long bits = (unsigned long long)o.x | ((unsigned long long)o.y << 32);
             uint32_t csize = 1;
             while ((bits & 1ull) && csize <= 64) { csize++; bits >>= 1; }
-            WSet bf, bn;
+            WSetW bf, bn;
             bf.o_key = R.o_bfk; bf.o_var = R.o_bfv; bf.o_w = R.o_bfw; bf.n = 0; bf.total = 0.0;
             bn.o_key = R.o_bnk; bn.o_var = 0xFFFFFFFFu; bn.o_w = R.o_bnw; bn.n = 0; bn.total = 0.0;
             uint32_t ncl = 0;
             auto in_cluster = [&](uint32_t var, uint32_t pos) -> bool { // popped flags of the boundary manager (:1038-1043)
-                for (uint32_t i = 0; i < ncl; ++i) {
-                    const uint32_t cf = LDSW(R.o_clf, i);
-                    if (pos != SSE_NO_VAR ? cf == pos : (cf == SSE_NO_VAR && LDSW(R.o_clv, i) == var)) return true;
+                for (uint32_t base = 0; base < ncl; base += 64u) {
+                    const uint32_t i = base + (uint32_t)lane, ii = i < ncl ? i : 0u;
+                    const uint32_t cf = LDSW(R.o_clf, ii), cv = LDSW(R.o_clv, ii);
+                    const bool hit = pos != SSE_NO_VAR ? cf == pos : (cf == SSE_NO_VAR && cv == var);
+                    if (sse_ballot((i < ncl) & hit)) return true;
                 }
                 return false;
             };
             auto push_adj = [&](uint32_t var, uint32_t pos, double w) {
                 if (in_cluster(var, pos)) return;
-                const bool ok = pos != SSE_NO_VAR ? bf.add(pos, var, w) : bn.add(var, var, w);
+                const bool ok = pos != SSE_NO_VAR ? bf.add(pos, var, w, lane) : bn.add(var, var, w, lane);
                 if (!ok) lerr = 7u;
             };
             push_adj(v0, f0, 1.0);
@@ -547,8 +661,8 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
                 if (bn.n == 0) pick_flips = true;
                 o = g.next();
                 uint32_t v, flip;
-                if (pick_flips) { const uint32_t idx = bf.pick(u01(o.x)); v = LDSW(bf.o_var, idx); flip = LDSW(bf.o_key, idx); bf.remove_at(idx); }
-                else { const uint32_t idx = bn.pick(u01(o.x)); v = LDSW(bn.o_key, idx); flip = SSE_NO_VAR; bn.remove_at(idx); }
+                if (pick_flips) { const uint32_t idx = bf.pick(u01(o.x), lane); v = LDSW(bf.o_var, idx); flip = LDSW(bf.o_key, idx); bf.remove_at(idx); }
+                else { const uint32_t idx = bn.pick(u01(o.x), lane); v = LDSW(bn.o_key, idx); flip = SSE_NO_VAR; bn.remove_at(idx); }
                 if (ncl >= SSE_RVB_MAXCL) { lerr = 7u; break; }
                 LDSW(R.o_clv, ncl) = v; LDSW(R.o_clf, ncl) = flip; ncl++;
                 const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
@@ -568,7 +682,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
                     else if (flip != SSE_NO_VAR) {
                         const uint32_t rel = flip - vs;
                         const uint32_t finc = (rel + 1) % vl + vs;
-                        rvb_overlaps(R, LDSW(R.o_cps, flip), LDSW(R.o_cps, finc), M, os, ol, [&](uint32_t ip) { push_adj(ov, ip + os, weight); });
+                        rvb_overlaps_w(R, LDSW(R.o_cps, flip), LDSW(R.o_cps, finc), M, os, ol, lane, [&](uint32_t ip) { push_adj(ov, ip + os, weight); });
                     } else {
                         for (uint32_t pi = os; pi < os + ol; ++pi) push_adj(ov, pi, weight);
                     }
@@ -576,20 +690,37 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
                 left--;
             }
             // ---- sub-variables: sorted union of cluster and remaining boundary variables (:155-172) ----
+            // candidates -> o_last; an entry that repeats an earlier one is marked, the others rank themselves among the
+            // unmarked ones (lane per candidate, the comparison partner is broadcast from LDS)
+            const uint32_t nc = ncl + bf.n + bn.n;
+            for (uint32_t base = 0; base < nc; base += 64u) {
+                const uint32_t i = base + (uint32_t)lane;
+                if (i < nc) LDSW(R.o_last, i) = i < ncl ? LDSW(R.o_clv, i) : (i < ncl + bf.n ? LDSW(bf.o_var, i - ncl) : LDSW(bn.o_key, i - ncl - bf.n));
+            }
+            SSE_WAVE_FENCE();
             uint32_t nsub = 0;
-            auto add_sub = [&](uint32_t v) { // sorted insert without duplicates
-                uint32_t i = 0;
-                while (i < nsub && LDSW(R.o_sub, i) < v) i++;
-                if (i < nsub && LDSW(R.o_sub, i) == v) return;
-                if (nsub >= SSE_RVB_MAXSUB) { lerr = 7u; return; }
-                for (uint32_t j = nsub; j > i; --j) LDSW(R.o_sub, j) = LDSW(R.o_sub, j - 1);
-                LDSW(R.o_sub, i) = v;
-                nsub++;
-            };
-            for (uint32_t i = 0; i < ncl; ++i) add_sub(LDSW(R.o_clv, i));
-            for (uint32_t i = 0; i < bf.n; ++i) add_sub(LDSW(bf.o_var, i));
-            for (uint32_t i = 0; i < bn.n; ++i) add_sub(LDSW(bn.o_key, i));
-            for (uint32_t s = 0; s < nsub; ++s) { LDSH(R.o_v2s, LDSW(R.o_sub, s)) = (uint16_t)s; LDSW(R.o_sfl, s) = 0u; }
+            {
+                const uint32_t DUP = 0x80000000u;
+                for (uint32_t base = 0; base < nc; base += 64u) { // mark repeats (variables are < 2^31)
+                    const uint32_t i = base + (uint32_t)lane;
+                    const uint32_t vi = LDSW(R.o_last, i < nc ? i : 0u) & ~DUP;
+                    bool dup = false;
+                    for (uint32_t j = 0; j < base + 64u && j < nc; ++j) dup |= (j < i) & ((LDSW(R.o_last, j) & ~DUP) == vi);
+                    SSE_WAVE_FENCE();
+                    if ((i < nc) & dup) LDSW(R.o_last, i) = vi | DUP;
+                    SSE_WAVE_FENCE();
+                }
+                for (uint32_t base = 0; base < nc; base += 64u) {
+                    const uint32_t i = base + (uint32_t)lane;
+                    const uint32_t xi = LDSW(R.o_last, i < nc ? i : 0u);
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < nc; ++j) rank += LDSW(R.o_last, j) < xi ? 1u : 0u; // marked entries compare high: never counted
+                    const bool keep = (i < nc) & !(xi & DUP);
+                    if (keep) { LDSW(R.o_sub, rank) = xi; LDSH(R.o_v2s, xi) = (uint16_t)rank; LDSW(R.o_sfl, rank) = 0u; }
+                    nsub += (uint32_t)popc64(sse_ballot(keep));
+                }
+                SSE_WAVE_FENCE();
+            }
             // ---- starting state and toggle positions (:174-196), sort, remove_doubles (:230-231) ----
             uint32_t ntog = 0;
             for (uint32_t i = 0; i < ncl && !lerr; ++i) {
@@ -600,11 +731,24 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
                     uint32_t t0 = LDSW(R.o_cps, fi), t1;
                     if (fi - vs + 1 >= vl) { LDSW(R.o_sfl, sv) |= 1u; t1 = LDSW(R.o_cps, vs); }
                     else t1 = LDSW(R.o_cps, fi + 1);
-                    for (int q = 0; q < 2; ++q) { // sorted insert
+                    for (int q = 0; q < 2; ++q) { // sorted insert: the entries above x move up by one (lane per entry)
                         const uint32_t x = q ? t1 : t0;
-                        uint32_t j = ntog;
-                        while (j > 0 && LDSW(R.o_tog, j - 1) > x) { LDSW(R.o_tog, j) = LDSW(R.o_tog, j - 1); j--; }
-                        LDSW(R.o_tog, j) = x;
+                        uint32_t pos = 0;
+                        for (uint32_t base = 0; base < ntog; base += 64u) {
+                            const uint32_t j = base + (uint32_t)lane;
+                            pos += (uint32_t)popc64(sse_ballot((j < ntog) & (LDSW(R.o_tog, j < ntog ? j : 0u) <= x)));
+                        }
+                        for (uint32_t top = ntog; top > pos; ) { // highest block first: every entry is read before its slot is overwritten
+                            const uint32_t lo = top - pos > 64u ? top - 64u : pos;
+                            const uint32_t j = lo + (uint32_t)lane;
+                            const uint32_t tp = LDSW(R.o_tog, j < top ? j : lo), ts = LDSW(R.o_togs, j < top ? j : lo);
+                            SSE_WAVE_FENCE();
+                            if (j < top) { LDSW(R.o_tog, j + 1) = tp; LDSW(R.o_togs, j + 1) = ts; }
+                            SSE_WAVE_FENCE();
+                            top = lo;
+                        }
+                        LDSW(R.o_tog, pos) = x; LDSW(R.o_togs, pos) = sv;
+                        SSE_WAVE_FENCE();
                         ntog++;
                     }
                 } else LDSW(R.o_sfl, sv) |= 1u;
@@ -613,28 +757,37 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
                 uint32_t ii = 0, jj = 0;
                 while (jj + 1 < ntog) {
                     if (LDSW(R.o_tog, jj) == LDSW(R.o_tog, jj + 1)) jj += 2;
-                    else { LDSW(R.o_tog, ii++) = LDSW(R.o_tog, jj++); }
+                    else { LDSW(R.o_tog, ii) = LDSW(R.o_tog, jj); LDSW(R.o_togs, ii) = LDSW(R.o_togs, jj); ii++; jj++; }
                 }
-                if (jj < ntog) LDSW(R.o_tog, ii++) = LDSW(R.o_tog, jj++);
+                if (jj < ntog) { LDSW(R.o_tog, ii) = LDSW(R.o_tog, jj); LDSW(R.o_togs, ii) = LDSW(R.o_togs, jj); ii++; jj++; }
                 ntog = ii;
             }
             // ---- windows where the cluster is non-empty (mutate_graph :310-360); cluster_state := starting state ----
             uint32_t count = 0, nwin = 0, nuntil = 0;
-            for (uint32_t s = 0; s < nsub; ++s) { const uint32_t f = LDSW(R.o_sfl, s) & 1u; LDSW(R.o_sfl, s) = f | (f << 1); count += f; }
+            for (uint32_t base = 0; base < nsub; base += 64u) {
+                const uint32_t sidx = base + (uint32_t)lane;
+                const uint32_t f = sidx < nsub ? LDSW(R.o_sfl, sidx) & 1u : 0u;
+                if (sidx < nsub) LDSW(R.o_sfl, sidx) = f | (f << 1);
+                count += (uint32_t)popc64(sse_ballot(f != 0u));
+            }
+            SSE_WAVE_FENCE();
             if (count) LDSW(R.o_wfrom, nwin++) = 0u;
             for (uint32_t i = 0; i < ntog && !lerr; ++i) {
                 const uint32_t p = LDSW(R.o_tog, i);
                 if (count == 0) { if (nwin >= SSE_RVB_MAXWIN) { lerr = 7u; break; } LDSW(R.o_wfrom, nwin++) = p; }
-                const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(ops[p]));
-                const uint32_t sv = v2s_get(R, d.a);
+                const uint32_t sv = LDSW(R.o_togs, i); // the toggle is a constant op of this cluster member
                 const uint32_t f = LDSW(R.o_sfl, sv) ^ 2u;
                 LDSW(R.o_sfl, sv) = f;
                 if (f & 2u) count++; else count--;
                 if (count == 0) LDSW(R.o_wuntil, nuntil++) = p;
             }
             if (count) LDSW(R.o_wuntil, nuntil++) = M;
+            SSE_WAVE_FENCE();
             // restore cluster_state = starting state for the probability pass
-            for (uint32_t s = 0; s < nsub; ++s) { const uint32_t f = LDSW(R.o_sfl, s) & 1u; LDSW(R.o_sfl, s) = f | (f << 1); }
+            for (uint32_t base = 0; base < nsub; base += 64u) {
+                const uint32_t sidx = base + (uint32_t)lane;
+                if (sidx < nsub) { const uint32_t f = LDSW(R.o_sfl, sidx) & 1u; LDSW(R.o_sfl, sidx) = f | (f << 1); }
+            }
             LDSW(R.o_ctl, RC_NSUB) = nsub;
             LDSW(R.o_ctl, RC_NWIN) = nwin;
             LDSW(R.o_ctl, 8) = ntog;
@@ -642,6 +795,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
             if (lerr) LDSW(R.o_ctl, RC_ERR) = lerr;
         }
         __syncthreads();
+        SSE_STAMP(7);
         if (LDSW(R.o_ctl, RC_ERR)) break;
         const uint32_t nsub = LDSW(R.o_ctl, RC_NSUB), nwin = LDSW(R.o_ctl, RC_NWIN), ntog = LDSW(R.o_ctl, 8);
         g.k = LDSW(R.o_ctl, 9);
@@ -655,12 +809,15 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
         for (uint32_t wi = 0; wi < nwin; ++wi) {
             const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
             rvb_state_at<W, CL>(B, L, R, r, from, nsub, false);
+            SSE_STAMP(8);
             if (tid == 0 && wi == 0 && from == 0 && !broke) {
                 if (!rvb_initial_bonds<CL, W>(B, L, R, nsub, bs, true)) LDSW(R.o_ctl, RC_ERR) = 7u;
             }
             uint32_t gp = from;
             for (;;) {
+                SSE_STAMP(10);
                 rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+                SSE_STAMP(9);
                 const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
                 gp = LDSW(R.o_ctl, RC_NEXTP);
                 if (tid == 0 && !broke && !LDSW(R.o_ctl, RC_ERR)) {
@@ -698,6 +855,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
             }
         }
         // ================= phase C: accept (:241-246) =================
+        SSE_STAMP(10);
         if (tid == 0) {
             if (!(nb == 0 || fabs(bs.tb - bs.ta) < 2.220446049250313e-16)) mult *= powi_sq(bs.ta / bs.tb, nb);
             const uint4 o = g.next();
@@ -706,6 +864,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
             LDSW(R.o_ctl, 9) = g.k;
         }
         __syncthreads();
+        SSE_STAMP(11);
         if (LDSW(R.o_ctl, RC_ERR)) break;
         g.k = LDSW(R.o_ctl, 9);
         if (LDSW(R.o_ctl, RC_ACCEPT)) {
@@ -718,12 +877,15 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
             for (uint32_t wi = 0; wi < nwin; ++wi) {
                 const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
                 rvb_state_at<W, CL>(B, L, R, r, from, nsub, true); // substate ^= cluster_state (:396-399, :315-318)
+                SSE_STAMP(8);
                 if (tid == 0 && wi == 0 && from == 0) {
                     if (!rvb_initial_bonds<CL, W>(B, L, R, nsub, bs, false)) LDSW(R.o_ctl, RC_ERR) = 7u;
                 }
                 uint32_t gp = from;
                 for (;;) {
+                    SSE_STAMP(12);
                     rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+                    SSE_STAMP(9);
                     const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
                     gp = LDSW(R.o_ctl, RC_NEXTP);
                     if (tid == 0 && !LDSW(R.o_ctl, RC_ERR)) {
@@ -775,6 +937,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
                 }
             }
             __syncthreads();
+            SSE_STAMP(12);
             // p=0 state of the sub-variables that start inside the cluster (:266-274)
             for (uint32_t s = tid; s < nsub; s += blockDim.x)
                 if (LDSW(R.o_sfl, s) & 1u) { const uint32_t v = LDSW(R.o_sub, s); atomicXor(&LDSW(L.o_state, v >> 5), 1u << (v & 31)); }
