@@ -59,6 +59,8 @@ extern "C" {
 #define ISINGMC_CFG_COMPACT 64u /* experimental: the trimmed diagonal kernel also writes the occupied slots as a dense list and the cluster
                                    update of the same timestep scans that list (n instead of M elements; same results; on MI355X the two
                                    launches trade 0.1 ms for 0.1 ms, see DESIGN.md, so it is off by default) */
+#define ISINGMC_CFG_RVB_SERIAL_GROWTH 128u /* RVB sweeps grow the clusters of their attempts one at a time instead of a batch of them side by
+                                            side on the waves of the workgroup (testing: the results are the same either way) */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 

@@ -642,6 +642,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     for (uint32_t hI = 0; hI < nH && D.uniformJ; ++hI)
         for (uint32_t e = 0; e < D.E; ++e) if (tab[(size_t)hI * D.Nb + e].w != tab[0].w) { D.uniformJ = 0u; break; }
     b->fused_launch = (cfg->flags & ISINGMC_CFG_FUSED_LAUNCH) != 0;
+    D.rvb_growers = (cfg->flags & ISINGMC_CFG_RVB_SERIAL_GROWTH) ? 0u : 64u;
     const bool CL = !generic && !perJ && D.uniformJ && D.N <= SSE_CE_MAX_VARS && (size_t)D.E * 4 <= 48 * 1024 && !(cfg->flags & ISINGMC_CFG_NO_LDS_TABLES);
     const uint32_t ledges = CL ? D.E : 0u;
     // Per-variable scan tables: in LDS while W copies of them fit (with room for a union-find), otherwise in a per-replica

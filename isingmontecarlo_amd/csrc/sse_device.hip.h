@@ -84,6 +84,7 @@ struct DevBatch {
     uint32_t bond_stride; // 0, or Nb when every replica has its own bond table / cumulative weights (per-replica couplings)
     const double *wtot_r; // [R] per-replica total weight (bond_stride != 0)
     const uint32_t *adj_start, *adj; // [N+1], [2E] bonds_for_var (make_classical_bonds, qmc_ising.rs:421-432)
+    uint32_t rvb_growers; // RVB: attempts grown side by side (0 = one at a time on wave 0)
     uint32_t dbg_flags;   // diagnostic builds only
     unsigned long long *dbg; // [R][16] phase durations in 10-ns ticks (diagnostic builds only, -DSSE_PHASE_TIMING)
 };

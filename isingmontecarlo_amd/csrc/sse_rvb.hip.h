@@ -44,6 +44,7 @@ struct RvbLds { // word offsets into lds_raw
     uint32_t o_bk, o_bwb, o_bwa;  // boundary bonds: key, weight before, weight after
     uint32_t o_glp, o_glw;        // gathered ops: slot, word
     uint32_t o_ctl;     // [16] control words shared between the sequential lane and the workgroup
+    uint32_t o_gout;    // [8] results of a growth in the large area
     uint32_t o_cps;     // [cps_cap] constant-op positions grouped by variable
     uint32_t cps_cap;
     uint32_t adj_lds;
@@ -56,7 +57,7 @@ __device__ __forceinline__ double &ldsd(uint32_t off, uint32_t i) { return reint
 __host__ __device__ inline uint32_t rvb_fixed_words(uint32_t N, uint32_t E) {
     const uint32_t adj = (N < 65535u && E < 65535u) ? (N + 2) / 2 + E : 0u;
     return 1u + 4 * SSE_RVB_SETCAP + 4 * SSE_RVB_BONDCAP + (N + 1) + N + (N + 1) / 2 + adj + 3 * SSE_RVB_MAXSUB +
-           6 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 2 * SSE_RVB_GCAP + 16;
+           6 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 2 * SSE_RVB_GCAP + 16 + 8;
 }
 
 template <int W>
@@ -88,6 +89,7 @@ __device__ __forceinline__ void rvb_carve(RvbLds &R, const Lds<W> &L, const DevB
     R.o_glp = base; base += SSE_RVB_GCAP;
     R.o_glw = base; base += SSE_RVB_GCAP;
     R.o_ctl = base; base += 16;
+    R.o_gout = base; base += 8;
     R.o_cps = base;
     R.cps_cap = B.lds_words > base ? B.lds_words - base : 0u;
 }
@@ -188,7 +190,7 @@ __device__ __forceinline__ int wv_find(uint32_t o_key, uint32_t n, uint32_t key,
 // weighted candidate set of the boundary manager, run by a whole wave (same arithmetic, in the same order, as WSet)
 struct WSetW {
     uint32_t o_key, o_var, o_w; // o_var == 0xFFFFFFFF: the variable is the key
-    uint32_t n;
+    uint32_t n, cap;
     double total;
     __device__ __forceinline__ bool add(uint32_t key, uint32_t var, double w, int lane) { // BondContainer::insert of (existing weight + w) (rvb.rs:1044-1045)
         const int i = wv_find(o_key, n, key, lane);
@@ -198,7 +200,7 @@ struct WSetW {
             ldsd(o_w, i) = neww;
             return true;
         }
-        if (n >= SSE_RVB_SETCAP) return false;
+        if (n >= cap) return false;
         LDSW(o_key, n) = key;
         if (o_var != 0xFFFFFFFFu) LDSW(o_var, n) = var;
         const double neww = 0.0 + w;
@@ -591,214 +593,289 @@ __device__ __forceinline__ void rvb_state_at(const DevBatch &B, const Lds<W> &L,
 }
 
 // ---------------------------------------------------------------------------------------------
+// One attempt's growth products and scratch (word offsets into lds_raw).  The growth of an attempt reads only the
+// constant-op table, the adjacency and its own random numbers — never the op-string — so the attempts of a batch grow
+// side by side, one per wave, each into its own small area; an attempt whose cluster outgrows a small area is grown
+// again in the large one when its turn comes.
+struct GrowArea {
+    uint32_t o_bfk, o_bfv, o_bfw, o_bnk, o_bnw, o_clv, o_clf, o_sub, o_sfl, o_tmp, o_tog, o_togs, o_wfrom, o_wuntil, o_out;
+    uint32_t cap_set, cap_cl, cap_sub, cap_win;
+};
+enum { GO_NSUB = 0, GO_NWIN = 1, GO_NTOG = 2, GO_K = 3, GO_ERR = 4 };
+#define SSE_RVB_SLOT_SET 48u
+#define SSE_RVB_SLOT_CL 16u
+#define SSE_RVB_SLOT_SUB (SSE_RVB_SLOT_CL + 2u * SSE_RVB_SLOT_SET)
+#define SSE_RVB_SLOT_WIN (SSE_RVB_SLOT_CL + 2u)
+#define SSE_RVB_SLOT_WORDS (7u * SSE_RVB_SLOT_SET + 6u * SSE_RVB_SLOT_CL + 3u * SSE_RVB_SLOT_SUB + 2u * SSE_RVB_SLOT_WIN + 8u)
+__device__ __forceinline__ GrowArea grow_area_small(uint32_t base) { // base even (doubles)
+    GrowArea A;
+    A.cap_set = SSE_RVB_SLOT_SET; A.cap_cl = SSE_RVB_SLOT_CL; A.cap_sub = SSE_RVB_SLOT_SUB; A.cap_win = SSE_RVB_SLOT_WIN;
+    A.o_bfw = base; base += 2 * A.cap_set;
+    A.o_bnw = base; base += 2 * A.cap_set;
+    A.o_bfk = base; base += A.cap_set;
+    A.o_bfv = base; base += A.cap_set;
+    A.o_bnk = base; base += A.cap_set;
+    A.o_clv = base; base += A.cap_cl;
+    A.o_clf = base; base += A.cap_cl;
+    A.o_tog = base; base += 2 * A.cap_cl;
+    A.o_togs = base; base += 2 * A.cap_cl;
+    A.o_sub = base; base += A.cap_sub;
+    A.o_sfl = base; base += A.cap_sub;
+    A.o_tmp = base; base += A.cap_sub;
+    A.o_wfrom = base; base += A.cap_win;
+    A.o_wuntil = base; base += A.cap_win;
+    A.o_out = base;
+    return A;
+}
+__device__ __forceinline__ GrowArea grow_area_large(const RvbLds &R) {
+    GrowArea A;
+    A.cap_set = SSE_RVB_SETCAP; A.cap_cl = SSE_RVB_MAXCL; A.cap_sub = SSE_RVB_MAXSUB; A.cap_win = SSE_RVB_MAXWIN;
+    A.o_bfw = R.o_bfw; A.o_bnw = R.o_bnw; A.o_bfk = R.o_bfk; A.o_bfv = R.o_bfv; A.o_bnk = R.o_bnk;
+    A.o_clv = R.o_clv; A.o_clf = R.o_clf; A.o_tog = R.o_tog; A.o_togs = R.o_togs;
+    A.o_sub = R.o_sub; A.o_sfl = R.o_sfl; A.o_tmp = R.o_last; A.o_wfrom = R.o_wfrom; A.o_wuntil = R.o_wuntil;
+    A.o_out = R.o_gout;
+    return A;
+}
+
+// start, cluster growth, sub-variables, windows of one attempt (rvb.rs:88-232, :1054-1123); run by a whole wave, uniform
+template <int W, bool CL>
+__device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, const RvbLds &R, const GrowArea &A, RvbDraw g, uint32_t C, uint32_t nzero,
+                                         uint32_t M, int lane) {
+    const uint32_t N = B.N;
+    uint32_t lerr = 0;
+    uint4 o = g.next();
+    const uint32_t choice = __umulhi(o.x, C + nzero);
+    uint32_t v0, f0;
+    if (choice < C) { // the variable whose range of the position table holds `choice`: 64-way search
+        uint32_t lo = 0, hi = N; // vstart[lo] <= choice < vstart[hi]
+        while (hi - lo > 1u) {
+            const uint32_t step = (hi - lo + 63u) / 64u, idx = lo + (uint32_t)lane * step;
+            const uint32_t x = LDSW(R.o_vstart, idx < hi ? idx : lo);
+            const uint32_t cnt = (uint32_t)popc64(sse_ballot((idx < hi) & (x <= choice))); // a prefix of the lanes (lane 0 always)
+            const uint32_t nhi = lo + cnt * step;
+            lo += (cnt - 1u) * step;
+            hi = nhi < hi ? nhi : hi;
+        }
+        v0 = lo; f0 = choice;
+    } else { v0 = LDSW(R.o_zero, choice - C); f0 = SSE_NO_VAR; }
+    o = g.next();
+    unsigned long long bits = (unsigned long long)o.x | ((unsigned long long)o.y << 32);
+    uint32_t csize = 1;
+    while ((bits & 1ull) && csize <= 64) { csize++; bits >>= 1; }
+    WSetW bf, bn;
+    bf.o_key = A.o_bfk; bf.o_var = A.o_bfv; bf.o_w = A.o_bfw; bf.n = 0; bf.total = 0.0; bf.cap = A.cap_set;
+    bn.o_key = A.o_bnk; bn.o_var = 0xFFFFFFFFu; bn.o_w = A.o_bnw; bn.n = 0; bn.total = 0.0; bn.cap = A.cap_set;
+    uint32_t ncl = 0;
+    auto in_cluster = [&](uint32_t var, uint32_t pos) -> bool { // popped flags of the boundary manager (:1038-1043)
+        for (uint32_t base = 0; base < ncl; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane, ii = i < ncl ? i : 0u;
+            const uint32_t cf = LDSW(A.o_clf, ii), cv = LDSW(A.o_clv, ii);
+            const bool hit = pos != SSE_NO_VAR ? cf == pos : (cf == SSE_NO_VAR && cv == var);
+            if (sse_ballot((i < ncl) & hit)) return true;
+        }
+        return false;
+    };
+    auto push_adj = [&](uint32_t var, uint32_t pos, double w) {
+        if (in_cluster(var, pos)) return;
+        const bool ok = pos != SSE_NO_VAR ? bf.add(pos, var, w, lane) : bn.add(var, var, w, lane);
+        if (!ok) lerr = 7u;
+    };
+    push_adj(v0, f0, 1.0);
+    uint32_t left = csize;
+    while (left > 0 && (bf.n + bn.n) > 0 && !lerr) {
+        o = g.next();
+        const double f_ratio = bf.total / (bf.total + bn.total);
+        bool pick_flips = u01(o.x) < f_ratio;
+        if (bf.n == 0) pick_flips = false;
+        if (bn.n == 0) pick_flips = true;
+        o = g.next();
+        uint32_t v, flip;
+        if (pick_flips) { const uint32_t idx = bf.pick(u01(o.x), lane); v = LDSW(bf.o_var, idx); flip = LDSW(bf.o_key, idx); bf.remove_at(idx); }
+        else { const uint32_t idx = bn.pick(u01(o.x), lane); v = LDSW(bn.o_key, idx); flip = SSE_NO_VAR; bn.remove_at(idx); }
+        if (ncl >= A.cap_cl) { lerr = 7u; break; }
+        LDSW(A.o_clv, ncl) = v; LDSW(A.o_clf, ncl) = flip; ncl++;
+        const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
+        if (flip != SSE_NO_VAR) {
+            const uint32_t rel = flip - vs;
+            push_adj(v, (rel + vl - 1) % vl + vs, 1.0);
+            push_adj(v, (rel + 1) % vl + vs, 1.0);
+        }
+        const uint32_t i1 = adj_begin(R, B, v + 1);
+        for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
+            const uint32_t b = adj_at(R, B, i);
+            const Bd d = decode_bond<CL, W>(B, L, b);
+            const double weight = d.w * 0.5; // bond_mag = |J| (qmc_ising.rs:633-635)
+            const uint32_t ov = d.a == v ? d.c : d.a;
+            const uint32_t os = LDSW(R.o_vstart, ov), ol = LDSW(R.o_vstart, ov + 1) - os;
+            if (ol == 0) push_adj(ov, SSE_NO_VAR, weight);
+            else if (flip != SSE_NO_VAR) {
+                const uint32_t rel = flip - vs;
+                const uint32_t finc = (rel + 1) % vl + vs;
+                rvb_overlaps_w(R, LDSW(R.o_cps, flip), LDSW(R.o_cps, finc), M, os, ol, lane, [&](uint32_t ip) { push_adj(ov, ip + os, weight); });
+            } else {
+                for (uint32_t pi = os; pi < os + ol; ++pi) push_adj(ov, pi, weight);
+            }
+        }
+        left--;
+    }
+    // ---- sub-variables: sorted union of cluster and remaining boundary variables (:155-172) ----
+    // candidates -> o_last; an entry that repeats an earlier one is marked, the others rank themselves among the
+    // unmarked ones (lane per candidate, the comparison partner is broadcast from LDS)
+    const uint32_t nc = lerr ? 0u : ncl + bf.n + bn.n;
+    if (nc > A.cap_sub) lerr = 7u;
+    for (uint32_t base = 0; base < nc && !lerr; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        if (i < nc) LDSW(A.o_tmp, i) = i < ncl ? LDSW(A.o_clv, i) : (i < ncl + bf.n ? LDSW(bf.o_var, i - ncl) : LDSW(bn.o_key, i - ncl - bf.n));
+    }
+    SSE_WAVE_FENCE();
+    uint32_t nsub = 0;
+    if (!lerr) {
+        const uint32_t DUP = 0x80000000u;
+        for (uint32_t base = 0; base < nc; base += 64u) { // mark repeats (variables are < 2^31)
+            const uint32_t i = base + (uint32_t)lane;
+            const uint32_t vi = LDSW(A.o_tmp, i < nc ? i : 0u) & ~DUP;
+            bool dup = false;
+            for (uint32_t j = 0; j < base + 64u && j < nc; ++j) dup |= (j < i) & ((LDSW(A.o_tmp, j) & ~DUP) == vi);
+            SSE_WAVE_FENCE();
+            if ((i < nc) & dup) LDSW(A.o_tmp, i) = vi | DUP;
+            SSE_WAVE_FENCE();
+        }
+        for (uint32_t base = 0; base < nc; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane;
+            const uint32_t xi = LDSW(A.o_tmp, i < nc ? i : 0u);
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nc; ++j) rank += LDSW(A.o_tmp, j) < xi ? 1u : 0u; // marked entries compare high: never counted
+            const bool keep = (i < nc) & !(xi & DUP);
+            if (keep) { LDSW(A.o_sub, rank) = xi; LDSW(A.o_sfl, rank) = 0u; }
+            nsub += (uint32_t)popc64(sse_ballot(keep));
+        }
+        SSE_WAVE_FENCE();
+    }
+    // ---- starting state and toggle positions (:174-196), sort, remove_doubles (:230-231) ----
+    uint32_t ntog = 0;
+    for (uint32_t i = 0; i < ncl && !lerr; ++i) {
+        const uint32_t v = LDSW(A.o_clv, i), fi = LDSW(A.o_clf, i);
+        const uint32_t sv = (uint32_t)wv_find(A.o_sub, nsub, v, lane); // the list is this attempt's own: the shared var -> sub table is filled when its turn comes
+        if (fi != SSE_NO_VAR) {
+            const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
+            uint32_t t0 = LDSW(R.o_cps, fi), t1;
+            if (fi - vs + 1 >= vl) { LDSW(A.o_sfl, sv) |= 1u; t1 = LDSW(R.o_cps, vs); }
+            else t1 = LDSW(R.o_cps, fi + 1);
+            for (int q = 0; q < 2; ++q) { // sorted insert: the entries above x move up by one (lane per entry)
+                const uint32_t x = q ? t1 : t0;
+                uint32_t pos = 0;
+                for (uint32_t base = 0; base < ntog; base += 64u) {
+                    const uint32_t j = base + (uint32_t)lane;
+                    pos += (uint32_t)popc64(sse_ballot((j < ntog) & (LDSW(A.o_tog, j < ntog ? j : 0u) <= x)));
+                }
+                for (uint32_t top = ntog; top > pos; ) { // highest block first: every entry is read before its slot is overwritten
+                    const uint32_t lo = top - pos > 64u ? top - 64u : pos;
+                    const uint32_t j = lo + (uint32_t)lane;
+                    const uint32_t tp = LDSW(A.o_tog, j < top ? j : lo), ts = LDSW(A.o_togs, j < top ? j : lo);
+                    SSE_WAVE_FENCE();
+                    if (j < top) { LDSW(A.o_tog, j + 1) = tp; LDSW(A.o_togs, j + 1) = ts; }
+                    SSE_WAVE_FENCE();
+                    top = lo;
+                }
+                LDSW(A.o_tog, pos) = x; LDSW(A.o_togs, pos) = sv;
+                SSE_WAVE_FENCE();
+                ntog++;
+            }
+        } else LDSW(A.o_sfl, sv) |= 1u;
+    }
+    { // remove_doubles (util/vec_help.rs:4-24)
+        uint32_t ii = 0, jj = 0;
+        while (jj + 1 < ntog) {
+            if (LDSW(A.o_tog, jj) == LDSW(A.o_tog, jj + 1)) jj += 2;
+            else { LDSW(A.o_tog, ii) = LDSW(A.o_tog, jj); LDSW(A.o_togs, ii) = LDSW(A.o_togs, jj); ii++; jj++; }
+        }
+        if (jj < ntog) { LDSW(A.o_tog, ii) = LDSW(A.o_tog, jj); LDSW(A.o_togs, ii) = LDSW(A.o_togs, jj); ii++; jj++; }
+        ntog = ii;
+    }
+    // ---- windows where the cluster is non-empty (mutate_graph :310-360); cluster_state := starting state ----
+    uint32_t count = 0, nwin = 0, nuntil = 0;
+    for (uint32_t base = 0; base < nsub; base += 64u) {
+        const uint32_t sidx = base + (uint32_t)lane;
+        const uint32_t f = sidx < nsub ? LDSW(A.o_sfl, sidx) & 1u : 0u;
+        if (sidx < nsub) LDSW(A.o_sfl, sidx) = f | (f << 1);
+        count += (uint32_t)popc64(sse_ballot(f != 0u));
+    }
+    SSE_WAVE_FENCE();
+    if (count) LDSW(A.o_wfrom, nwin++) = 0u;
+    for (uint32_t i = 0; i < ntog && !lerr; ++i) {
+        const uint32_t p = LDSW(A.o_tog, i);
+        if (count == 0) { if (nwin >= A.cap_win) { lerr = 7u; break; } LDSW(A.o_wfrom, nwin++) = p; }
+        const uint32_t sv = LDSW(A.o_togs, i); // the toggle is a constant op of this cluster member
+        const uint32_t f = LDSW(A.o_sfl, sv) ^ 2u;
+        LDSW(A.o_sfl, sv) = f;
+        if (f & 2u) count++; else count--;
+        if (count == 0) LDSW(A.o_wuntil, nuntil++) = p;
+    }
+    if (count) LDSW(A.o_wuntil, nuntil++) = M;
+    SSE_WAVE_FENCE();
+    // restore cluster_state = starting state for the probability pass
+    for (uint32_t base = 0; base < nsub; base += 64u) {
+        const uint32_t sidx = base + (uint32_t)lane;
+        if (sidx < nsub) { const uint32_t f = LDSW(A.o_sfl, sidx) & 1u; LDSW(A.o_sfl, sidx) = f | (f << 1); }
+    }
+    LDSW(A.o_out, GO_NSUB) = nsub;
+    LDSW(A.o_out, GO_NWIN) = nwin;
+    LDSW(A.o_out, GO_NTOG) = ntog;
+    LDSW(A.o_out, GO_K) = g.k;
+    LDSW(A.o_out, GO_ERR) = lerr;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int W, bool CL>
 __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, uint64_t epoch, uint32_t M, uint32_t updates,
                                              uint32_t &gr, uint32_t &err) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t N = B.N;
     uint32_t *ops = B.ops + (size_t)r * B.stride;
-    RvbLds R;
-    rvb_carve<W>(R, L, B);
-    if (tid == 0) LDSW(R.o_ctl, RC_ERR) = 0u;
+    RvbLds R0;
+    rvb_carve<W>(R0, L, B);
+    if (tid == 0) LDSW(R0.o_ctl, RC_ERR) = 0u;
     __syncthreads();
     SSE_STAMP_INIT; // diagnostic builds: 6 constants table, 7 growth, 8 states, 9 gathers, 10 replay (probability), 11 accept, 12 replay (mutation)
-    const uint32_t C = rvb_find_constants<W, CL>(B, L, R, r, M);
+    const uint32_t C = rvb_find_constants<W, CL>(B, L, R0, r, M);
     SSE_STAMP(6);
     if (C == 0xFFFFFFFFu) { err = 6u; return 0u; } // constant-op table does not fit in LDS
-    const uint32_t nzero = LDSW(R.o_ctl, RC_NZERO);
+    const uint32_t nzero = LDSW(R0.o_ctl, RC_NZERO);
     uint32_t nsucc = 0;
+    // small growth areas behind the used part of the constant-op table: as many as fit, at most one per wave
+    const uint32_t slots0 = (R0.o_cps + C + 1u) & ~1u;
+    uint32_t P = B.lds_words > slots0 ? (B.lds_words - slots0) / SSE_RVB_SLOT_WORDS : 0u;
+    if (P > (uint32_t)W) P = (uint32_t)W;
+    if (P > B.rvb_growers) P = B.rvb_growers;
+    const uint32_t PB = P ? P : 1u; // attempts per batch
+    const GrowArea big = grow_area_large(R0);
+    bool stop = false;
 
-    for (uint32_t attempt = 0; attempt < updates; ++attempt) {
+    for (uint32_t a0 = 0; a0 < updates && !stop; a0 += PB) {
+    if (P && (uint32_t)wave < P && a0 + (uint32_t)wave < updates) {
+        RvbDraw g;
+        g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.rid ? B.rid[r] : B.replica_offset + r; g.epoch_lo = (uint32_t)epoch; g.attempt = a0 + (uint32_t)wave; g.k = 0;
+        rvb_grow<W, CL>(B, L, R0, grow_area_small(slots0 + (uint32_t)wave * SSE_RVB_SLOT_WORDS), g, C, nzero, M, lane);
+    }
+    __syncthreads();
+    SSE_STAMP(7);
+    for (uint32_t aj = 0; aj < PB && a0 + aj < updates; ++aj) {
+        const uint32_t attempt = a0 + aj;
         RvbDraw g;
         g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.rid ? B.rid[r] : B.replica_offset + r; g.epoch_lo = (uint32_t)epoch; g.attempt = attempt; g.k = 0;
-        // ================= phase A (one wave, uniform): start, cluster growth, sub-variables, windows =================
-        if (wave == 0) {
-            uint32_t lerr = 0;
-            uint4 o = g.next();
-            const uint32_t choice = __umulhi(o.x, C + nzero);
-            uint32_t v0, f0;
-            if (choice < C) { // the variable whose range of the position table holds `choice`: 64-way search
-                uint32_t lo = 0, hi = N; // vstart[lo] <= choice < vstart[hi]
-                while (hi - lo > 1u) {
-                    const uint32_t step = (hi - lo + 63u) / 64u, idx = lo + (uint32_t)lane * step;
-                    const uint32_t x = LDSW(R.o_vstart, idx < hi ? idx : lo);
-                    const uint32_t cnt = (uint32_t)popc64(sse_ballot((idx < hi) & (x <= choice))); // a prefix of the lanes (lane 0 always)
-                    const uint32_t nhi = lo + cnt * step;
-                    lo += (cnt - 1u) * step;
-                    hi = nhi < hi ? nhi : hi;
-                }
-                v0 = lo; f0 = choice;
-            } else { v0 = LDSW(R.o_zero, choice - C); f0 = SSE_NO_VAR; }
-            o = g.next();
-            unsigned long long bits = (unsigned long long)o.x | ((unsigned long long)o.y << 32);
-            uint32_t csize = 1;
-            while ((bits & 1ull) && csize <= 64) { csize++; bits >>= 1; }
-            WSetW bf, bn;
-            bf.o_key = R.o_bfk; bf.o_var = R.o_bfv; bf.o_w = R.o_bfw; bf.n = 0; bf.total = 0.0;
-            bn.o_key = R.o_bnk; bn.o_var = 0xFFFFFFFFu; bn.o_w = R.o_bnw; bn.n = 0; bn.total = 0.0;
-            uint32_t ncl = 0;
-            auto in_cluster = [&](uint32_t var, uint32_t pos) -> bool { // popped flags of the boundary manager (:1038-1043)
-                for (uint32_t base = 0; base < ncl; base += 64u) {
-                    const uint32_t i = base + (uint32_t)lane, ii = i < ncl ? i : 0u;
-                    const uint32_t cf = LDSW(R.o_clf, ii), cv = LDSW(R.o_clv, ii);
-                    const bool hit = pos != SSE_NO_VAR ? cf == pos : (cf == SSE_NO_VAR && cv == var);
-                    if (sse_ballot((i < ncl) & hit)) return true;
-                }
-                return false;
-            };
-            auto push_adj = [&](uint32_t var, uint32_t pos, double w) {
-                if (in_cluster(var, pos)) return;
-                const bool ok = pos != SSE_NO_VAR ? bf.add(pos, var, w, lane) : bn.add(var, var, w, lane);
-                if (!ok) lerr = 7u;
-            };
-            push_adj(v0, f0, 1.0);
-            uint32_t left = csize;
-            while (left > 0 && (bf.n + bn.n) > 0 && !lerr) {
-                o = g.next();
-                const double f_ratio = bf.total / (bf.total + bn.total);
-                bool pick_flips = u01(o.x) < f_ratio;
-                if (bf.n == 0) pick_flips = false;
-                if (bn.n == 0) pick_flips = true;
-                o = g.next();
-                uint32_t v, flip;
-                if (pick_flips) { const uint32_t idx = bf.pick(u01(o.x), lane); v = LDSW(bf.o_var, idx); flip = LDSW(bf.o_key, idx); bf.remove_at(idx); }
-                else { const uint32_t idx = bn.pick(u01(o.x), lane); v = LDSW(bn.o_key, idx); flip = SSE_NO_VAR; bn.remove_at(idx); }
-                if (ncl >= SSE_RVB_MAXCL) { lerr = 7u; break; }
-                LDSW(R.o_clv, ncl) = v; LDSW(R.o_clf, ncl) = flip; ncl++;
-                const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
-                if (flip != SSE_NO_VAR) {
-                    const uint32_t rel = flip - vs;
-                    push_adj(v, (rel + vl - 1) % vl + vs, 1.0);
-                    push_adj(v, (rel + 1) % vl + vs, 1.0);
-                }
-                const uint32_t i1 = adj_begin(R, B, v + 1);
-                for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
-                    const uint32_t b = adj_at(R, B, i);
-                    const Bd d = decode_bond<CL, W>(B, L, b);
-                    const double weight = d.w * 0.5; // bond_mag = |J| (qmc_ising.rs:633-635)
-                    const uint32_t ov = d.a == v ? d.c : d.a;
-                    const uint32_t os = LDSW(R.o_vstart, ov), ol = LDSW(R.o_vstart, ov + 1) - os;
-                    if (ol == 0) push_adj(ov, SSE_NO_VAR, weight);
-                    else if (flip != SSE_NO_VAR) {
-                        const uint32_t rel = flip - vs;
-                        const uint32_t finc = (rel + 1) % vl + vs;
-                        rvb_overlaps_w(R, LDSW(R.o_cps, flip), LDSW(R.o_cps, finc), M, os, ol, lane, [&](uint32_t ip) { push_adj(ov, ip + os, weight); });
-                    } else {
-                        for (uint32_t pi = os; pi < os + ol; ++pi) push_adj(ov, pi, weight);
-                    }
-                }
-                left--;
-            }
-            // ---- sub-variables: sorted union of cluster and remaining boundary variables (:155-172) ----
-            // candidates -> o_last; an entry that repeats an earlier one is marked, the others rank themselves among the
-            // unmarked ones (lane per candidate, the comparison partner is broadcast from LDS)
-            const uint32_t nc = ncl + bf.n + bn.n;
-            for (uint32_t base = 0; base < nc; base += 64u) {
-                const uint32_t i = base + (uint32_t)lane;
-                if (i < nc) LDSW(R.o_last, i) = i < ncl ? LDSW(R.o_clv, i) : (i < ncl + bf.n ? LDSW(bf.o_var, i - ncl) : LDSW(bn.o_key, i - ncl - bf.n));
-            }
-            SSE_WAVE_FENCE();
-            uint32_t nsub = 0;
-            {
-                const uint32_t DUP = 0x80000000u;
-                for (uint32_t base = 0; base < nc; base += 64u) { // mark repeats (variables are < 2^31)
-                    const uint32_t i = base + (uint32_t)lane;
-                    const uint32_t vi = LDSW(R.o_last, i < nc ? i : 0u) & ~DUP;
-                    bool dup = false;
-                    for (uint32_t j = 0; j < base + 64u && j < nc; ++j) dup |= (j < i) & ((LDSW(R.o_last, j) & ~DUP) == vi);
-                    SSE_WAVE_FENCE();
-                    if ((i < nc) & dup) LDSW(R.o_last, i) = vi | DUP;
-                    SSE_WAVE_FENCE();
-                }
-                for (uint32_t base = 0; base < nc; base += 64u) {
-                    const uint32_t i = base + (uint32_t)lane;
-                    const uint32_t xi = LDSW(R.o_last, i < nc ? i : 0u);
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < nc; ++j) rank += LDSW(R.o_last, j) < xi ? 1u : 0u; // marked entries compare high: never counted
-                    const bool keep = (i < nc) & !(xi & DUP);
-                    if (keep) { LDSW(R.o_sub, rank) = xi; LDSH(R.o_v2s, xi) = (uint16_t)rank; LDSW(R.o_sfl, rank) = 0u; }
-                    nsub += (uint32_t)popc64(sse_ballot(keep));
-                }
-                SSE_WAVE_FENCE();
-            }
-            // ---- starting state and toggle positions (:174-196), sort, remove_doubles (:230-231) ----
-            uint32_t ntog = 0;
-            for (uint32_t i = 0; i < ncl && !lerr; ++i) {
-                const uint32_t v = LDSW(R.o_clv, i), fi = LDSW(R.o_clf, i);
-                const uint32_t sv = v2s_get(R, v);
-                if (fi != SSE_NO_VAR) {
-                    const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
-                    uint32_t t0 = LDSW(R.o_cps, fi), t1;
-                    if (fi - vs + 1 >= vl) { LDSW(R.o_sfl, sv) |= 1u; t1 = LDSW(R.o_cps, vs); }
-                    else t1 = LDSW(R.o_cps, fi + 1);
-                    for (int q = 0; q < 2; ++q) { // sorted insert: the entries above x move up by one (lane per entry)
-                        const uint32_t x = q ? t1 : t0;
-                        uint32_t pos = 0;
-                        for (uint32_t base = 0; base < ntog; base += 64u) {
-                            const uint32_t j = base + (uint32_t)lane;
-                            pos += (uint32_t)popc64(sse_ballot((j < ntog) & (LDSW(R.o_tog, j < ntog ? j : 0u) <= x)));
-                        }
-                        for (uint32_t top = ntog; top > pos; ) { // highest block first: every entry is read before its slot is overwritten
-                            const uint32_t lo = top - pos > 64u ? top - 64u : pos;
-                            const uint32_t j = lo + (uint32_t)lane;
-                            const uint32_t tp = LDSW(R.o_tog, j < top ? j : lo), ts = LDSW(R.o_togs, j < top ? j : lo);
-                            SSE_WAVE_FENCE();
-                            if (j < top) { LDSW(R.o_tog, j + 1) = tp; LDSW(R.o_togs, j + 1) = ts; }
-                            SSE_WAVE_FENCE();
-                            top = lo;
-                        }
-                        LDSW(R.o_tog, pos) = x; LDSW(R.o_togs, pos) = sv;
-                        SSE_WAVE_FENCE();
-                        ntog++;
-                    }
-                } else LDSW(R.o_sfl, sv) |= 1u;
-            }
-            { // remove_doubles (util/vec_help.rs:4-24)
-                uint32_t ii = 0, jj = 0;
-                while (jj + 1 < ntog) {
-                    if (LDSW(R.o_tog, jj) == LDSW(R.o_tog, jj + 1)) jj += 2;
-                    else { LDSW(R.o_tog, ii) = LDSW(R.o_tog, jj); LDSW(R.o_togs, ii) = LDSW(R.o_togs, jj); ii++; jj++; }
-                }
-                if (jj < ntog) { LDSW(R.o_tog, ii) = LDSW(R.o_tog, jj); LDSW(R.o_togs, ii) = LDSW(R.o_togs, jj); ii++; jj++; }
-                ntog = ii;
-            }
-            // ---- windows where the cluster is non-empty (mutate_graph :310-360); cluster_state := starting state ----
-            uint32_t count = 0, nwin = 0, nuntil = 0;
-            for (uint32_t base = 0; base < nsub; base += 64u) {
-                const uint32_t sidx = base + (uint32_t)lane;
-                const uint32_t f = sidx < nsub ? LDSW(R.o_sfl, sidx) & 1u : 0u;
-                if (sidx < nsub) LDSW(R.o_sfl, sidx) = f | (f << 1);
-                count += (uint32_t)popc64(sse_ballot(f != 0u));
-            }
-            SSE_WAVE_FENCE();
-            if (count) LDSW(R.o_wfrom, nwin++) = 0u;
-            for (uint32_t i = 0; i < ntog && !lerr; ++i) {
-                const uint32_t p = LDSW(R.o_tog, i);
-                if (count == 0) { if (nwin >= SSE_RVB_MAXWIN) { lerr = 7u; break; } LDSW(R.o_wfrom, nwin++) = p; }
-                const uint32_t sv = LDSW(R.o_togs, i); // the toggle is a constant op of this cluster member
-                const uint32_t f = LDSW(R.o_sfl, sv) ^ 2u;
-                LDSW(R.o_sfl, sv) = f;
-                if (f & 2u) count++; else count--;
-                if (count == 0) LDSW(R.o_wuntil, nuntil++) = p;
-            }
-            if (count) LDSW(R.o_wuntil, nuntil++) = M;
-            SSE_WAVE_FENCE();
-            // restore cluster_state = starting state for the probability pass
-            for (uint32_t base = 0; base < nsub; base += 64u) {
-                const uint32_t sidx = base + (uint32_t)lane;
-                if (sidx < nsub) { const uint32_t f = LDSW(R.o_sfl, sidx) & 1u; LDSW(R.o_sfl, sidx) = f | (f << 1); }
-            }
-            LDSW(R.o_ctl, RC_NSUB) = nsub;
-            LDSW(R.o_ctl, RC_NWIN) = nwin;
-            LDSW(R.o_ctl, 8) = ntog;
-            LDSW(R.o_ctl, 9) = g.k;
-            if (lerr) LDSW(R.o_ctl, RC_ERR) = lerr;
+        GrowArea A = P ? grow_area_small(slots0 + aj * SSE_RVB_SLOT_WORDS) : big;
+        if (!P || LDSW(A.o_out, GO_ERR)) { // no room for small areas, or this cluster outgrew its own: the large area
+            A = big;
+            if (wave == 0) rvb_grow<W, CL>(B, L, R0, big, g, C, nzero, M, lane);
+            __syncthreads();
+            SSE_STAMP(7);
         }
+        if (LDSW(A.o_out, GO_ERR)) { if (tid == 0) LDSW(R0.o_ctl, RC_ERR) = LDSW(A.o_out, GO_ERR); __syncthreads(); stop = true; break; }
+        const uint32_t nsub = LDSW(A.o_out, GO_NSUB), nwin = LDSW(A.o_out, GO_NWIN), ntog = LDSW(A.o_out, GO_NTOG);
+        g.k = LDSW(A.o_out, GO_K);
+        RvbLds R = R0; // this attempt's lists
+        R.o_sub = A.o_sub; R.o_sfl = A.o_sfl; R.o_tog = A.o_tog; R.o_togs = A.o_togs; R.o_wfrom = A.o_wfrom; R.o_wuntil = A.o_wuntil;
+        for (uint32_t s = tid; s < nsub; s += blockDim.x) LDSH(R0.o_v2s, LDSW(A.o_sub, s)) = (uint16_t)s;
         __syncthreads();
-        SSE_STAMP(7);
-        if (LDSW(R.o_ctl, RC_ERR)) break;
-        const uint32_t nsub = LDSW(R.o_ctl, RC_NSUB), nwin = LDSW(R.o_ctl, RC_NWIN), ntog = LDSW(R.o_ctl, 8);
-        g.k = LDSW(R.o_ctl, 9);
 
         // ================= phase B: calculate_flip_prob (rvb.rs:649-946) over the windows =================
         double mult = 1.0;          // meaningful on the sequential lane
@@ -865,7 +942,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
         }
         __syncthreads();
         SSE_STAMP(11);
-        if (LDSW(R.o_ctl, RC_ERR)) break;
+        if (LDSW(R.o_ctl, RC_ERR)) { stop = true; break; }
         g.k = LDSW(R.o_ctl, 9);
         if (LDSW(R.o_ctl, RC_ACCEPT)) {
             // ================= phase D: mutate_graph (:294-615) =================
@@ -946,10 +1023,11 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
         __syncthreads();
         for (uint32_t s = tid; s < nsub; s += blockDim.x) LDSH(R.o_v2s, LDSW(R.o_sub, s)) = (uint16_t)0xFFFFu;
         __syncthreads();
-        if (LDSW(R.o_ctl, RC_ERR)) break;
-    }
+        if (LDSW(R.o_ctl, RC_ERR)) { stop = true; break; }
+    } // attempts of the batch, in order
+    } // batches
     __syncthreads();
-    if (LDSW(R.o_ctl, RC_ERR)) err = LDSW(R.o_ctl, RC_ERR);
+    if (LDSW(R0.o_ctl, RC_ERR)) err = LDSW(R0.o_ctl, RC_ERR);
     __syncthreads();
     return nsucc;
 }

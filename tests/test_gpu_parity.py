@@ -206,10 +206,11 @@ RVB_CASES = [
     ("villain3", lat.two_d_periodic(3), 1.0, 0.0, 1.5, 9),
     ("villain4", lat.two_d_periodic(4), 1.0, 0.0, 2.0, 16),
     ("ferro8x8", lat.two_d_ferro(8), 1.0, 0.0, 3.0, 64),
+    ("ferro16x16_b4", lat.two_d_ferro(16), 1.0, 0.0, 4.0, 256),  # thousands of attempts: clusters that outgrow a small growth area
 ]
 
 
-@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (1, 1, 1), (4, 2, 0)])
+@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (1, 1, 1), (4, 2, 0), (0, 0, 128)])  # 128: attempts grown one at a time
 @pytest.mark.parametrize("name,edges,gamma,h,beta,cutoff", RVB_CASES, ids=[c[0] for c in RVB_CASES])
 def test_rvb_update_matches_oracle(oracle, name, edges, gamma, h, beta, cutoff, waves, k, cfgf):
     """RvbUpdater::rvb_update (rvb.rs:88-290): attempt by attempt identical to the oracle (ops, state, successes)."""
