@@ -42,14 +42,19 @@ struct RvbLds { // word offsets into lds_raw
     uint32_t o_bfk, o_bfv, o_bfw; // flips set: key (= flip index), var, weight (double = 2 words)
     uint32_t o_bnk, o_bnw;        // no-flips set: key (= var), weight
     uint32_t o_bk, o_bwb, o_bwa;  // boundary bonds: key, weight before, weight after
-    uint32_t o_glp, o_glw;        // gathered ops: slot, word
+    uint32_t o_glp, o_glw, o_gli; // gathered ops: slot, word, sub-variables and kind (SSE_GI_*)
+    uint32_t o_bix;     // [E] u16: entry of each edge in the boundary-bond set, 0xFFFF = absent (probability pass)
     uint32_t o_ctl;     // [16] control words shared between the sequential lane and the workgroup
     uint32_t o_gout;    // [8] results of a growth in the large area
     uint32_t o_cps;     // [cps_cap] constant-op positions grouped by variable
     uint32_t cps_cap;
     uint32_t adj_lds;
 };
-enum { RC_NSUB = 0, RC_NWIN = 1, RC_ACCEPT = 2, RC_GLEN = 3, RC_NEXTP = 4, RC_ERR = 5, RC_NZERO = 6, RC_SKIP = 7 };
+// gathered-op info word: sub-variable of the first / second leg (SSE_GI_NONE = not a sub-variable), bond kind, two-site bit
+#define SSE_GI_NONE 0x3FFu
+#define SSE_GI_KIND_SHIFT 20
+#define SSE_GI_TWO (1u << 22)
+enum { RC_NSUB = 0, RC_NWIN = 1, RC_ACCEPT = 2, RC_GLEN = 3, RC_NEXTP = 4, RC_ERR = 5, RC_NZERO = 6, RC_SKIP = 7, RC_BROKE = 10 };
 
 __device__ __forceinline__ double &ldsd(uint32_t off, uint32_t i) { return reinterpret_cast<double *>(lds_raw)[(off >> 1) + i]; }
 
@@ -57,7 +62,7 @@ __device__ __forceinline__ double &ldsd(uint32_t off, uint32_t i) { return reint
 __host__ __device__ inline uint32_t rvb_fixed_words(uint32_t N, uint32_t E) {
     const uint32_t adj = (N < 65535u && E < 65535u) ? (N + 2) / 2 + E : 0u;
     return 1u + 4 * SSE_RVB_SETCAP + 4 * SSE_RVB_BONDCAP + (N + 1) + N + (N + 1) / 2 + adj + 3 * SSE_RVB_MAXSUB +
-           6 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 2 * SSE_RVB_GCAP + 16 + 8;
+           6 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 3 * SSE_RVB_GCAP + (E + 1) / 2 + 16 + 8;
 }
 
 template <int W>
@@ -88,6 +93,8 @@ __device__ __forceinline__ void rvb_carve(RvbLds &R, const Lds<W> &L, const DevB
     R.o_bk = base; base += SSE_RVB_BONDCAP;
     R.o_glp = base; base += SSE_RVB_GCAP;
     R.o_glw = base; base += SSE_RVB_GCAP;
+    R.o_gli = base; base += SSE_RVB_GCAP;
+    R.o_bix = base; base += (B.E + 1) / 2;
     R.o_ctl = base; base += 16;
     R.o_gout = base; base += 8;
     R.o_cps = base;
@@ -352,6 +359,89 @@ __device__ __forceinline__ bool rvb_initial_bonds(const DevBatch &B, const Lds<W
     return true;
 }
 
+// boundary-bond set run by a whole wave (probability pass): the entries of BSet, found through the edge -> entry table
+struct BSetW {
+    uint32_t o_key, o_wb, o_wa, o_ix;
+    uint32_t n;
+    double tb, ta;
+    __device__ __forceinline__ bool insert(uint32_t key, double wb, double wa) {
+        const uint32_t i = (uint32_t)LDSH(o_ix, key);
+        if (i != 0xFFFFu) {
+            const double ob = ldsd(o_wb, i), oa = ldsd(o_wa, i);
+            tb += wb - ob; ldsd(o_wb, i) = wb;
+            ta += wa - oa; ldsd(o_wa, i) = wa;
+            return true;
+        }
+        if (n >= SSE_RVB_BONDCAP) return false;
+        LDSW(o_key, n) = key; ldsd(o_wb, n) = wb; ldsd(o_wa, n) = wa;
+        LDSH(o_ix, key) = (uint16_t)n;
+        tb += wb; ta += wa;
+        n++;
+        return true;
+    }
+    __device__ __forceinline__ void remove(uint32_t key) {
+        const uint32_t i = (uint32_t)LDSH(o_ix, key);
+        if (i == 0xFFFFu) return;
+        const uint32_t last = n - 1;
+        const double wb = ldsd(o_wb, i), wa = ldsd(o_wa, i), wbl = ldsd(o_wb, last), wal = ldsd(o_wa, last);
+        const uint32_t kl = LDSW(o_key, last);
+        LDSW(o_key, i) = kl; ldsd(o_wb, i) = wbl; ldsd(o_wa, i) = wal;
+        LDSH(o_ix, kl) = (uint16_t)i;
+        LDSH(o_ix, key) = (uint16_t)0xFFFFu; // after the line above: the removed entry may be the last one itself
+        n--;
+        tb -= wb; if (tb < 0.0) tb = 0.0;
+        ta -= wa; if (ta < 0.0) ta = 0.0;
+    }
+    __device__ __forceinline__ void clear(int lane) { // leave the table all-absent for the next attempt
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane;
+            if (i < n) LDSH(o_ix, LDSW(o_key, i)) = (uint16_t)0xFFFFu;
+        }
+        n = 0; tb = 0.0; ta = 0.0;
+    }
+};
+
+// rvb_update_bonds / one variable of rvb_initial_bonds by a whole wave: lane k fetches neighbour k of v and works out what
+// happens to their bond; the set is then changed in neighbour order.  initial: only bonds from the cluster to outside it
+// are inserted (set_initial_bonds, rvb.rs:617-645), nothing is removed.
+template <bool CL, int W>
+__device__ __forceinline__ bool rvb_update_bonds_w(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t v, BSetW &bs, bool initial, int lane) {
+    const uint32_t sv = v2s_get(R, v);
+    if (sv == 0xFFFFu) return true;
+    const uint32_t fv = LDSW(R.o_sfl, sv);
+    const uint32_t i0 = adj_begin(R, B, v), i1 = adj_begin(R, B, v + 1);
+    for (uint32_t base = i0; base < i1; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool in = i < i1;
+        const uint32_t b = adj_at(R, B, in ? i : i0);
+        const Bd d = decode_bond<CL, W>(B, L, b);
+        const uint32_t ov = d.a == v ? d.c : d.a;
+        const uint32_t so = v2s_get(R, ov);
+        const bool has = in & (so != 0xFFFFu);
+        const uint32_t fo = LDSW(R.o_sfl, has ? so : 0u);
+        const bool same = ((fv ^ fo) & 2u) == 0u;
+        const uint32_t act = !has ? 0u : (initial ? ((fo & 2u) ? 0u : 2u) : (same ? 1u : 2u)); // 1 remove, 2 insert
+        const uint32_t sa = d.a == v ? sv : so; // sub-variables of the bond's first / second site
+        const uint32_t fa = d.a == v ? fv : fo, fb = d.a == v ? fo : fv;
+        uint32_t ba = (fa >> 2) & 1u, bb = (fb >> 2) & 1u;
+        const uint32_t s0 = ba | (bb << 1);
+        const double wbef = bond_weight(d, s0, s0);
+        const uint32_t flipsub = (fv & 2u) ? sv : so; // ws_for_flip (:665-683): flip the variable that is inside the cluster
+        if (flipsub == sa) ba ^= 1u; else bb ^= 1u;
+        const uint32_t s1 = ba | (bb << 1);
+        const double waft = bond_weight(d, s1, s1);
+        uint64_t m = sse_ballot(act != 0u);
+        while (m) {
+            const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
+            m &= m - 1;
+            const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)k), ak = (uint32_t)__builtin_amdgcn_readlane((int)act, (int)k);
+            if (ak == 1u) bs.remove(bk);
+            else if (!bs.insert(bk, readlane_f64(wbef, k), readlane_f64(waft, k))) return false;
+        }
+    }
+    return true;
+}
+
 // find_overlapping_starts (rvb.rs:1125-1158) over cps[fp0 .. fp0+Lf); calls f(index) for each overlapping segment
 template <typename F>
 __device__ __forceinline__ void rvb_overlaps(const RvbLds &R, uint32_t p_start, uint32_t p_end, uint32_t cutoff, uint32_t fp0, uint32_t Lf, F f) {
@@ -489,7 +579,7 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
     const uint32_t last = until < M ? until : M - 1; // inclusive
     uint32_t glen = 0, next = gp;
     while (M != 0u && next <= last) {
-        uint32_t wd[U];
+        uint32_t wd[U], info[U];
         uint64_t mm[U];
         int cnt = 0;
 #pragma unroll
@@ -500,9 +590,13 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             bool match = false;
+            info[j] = 0u;
             if (wd[j]) {
                 const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
-                match = v2s_get(R, d.a) != 0xFFFFu || (d.c != SSE_NO_VAR && v2s_get(R, d.c) != 0xFFFFu);
+                const bool two = d.c != SSE_NO_VAR;
+                const uint32_t sa = v2s_get(R, d.a), sc = two ? v2s_get(R, d.c) : 0xFFFFu;
+                match = sa != 0xFFFFu || sc != 0xFFFFu;
+                info[j] = (sa != 0xFFFFu ? sa : SSE_GI_NONE) | ((sc != 0xFFFFu ? sc : SSE_GI_NONE) << 10) | (bd_kind(d) << SSE_GI_KIND_SHIFT) | (two ? SSE_GI_TWO : 0u);
             }
             mm[j] = sse_ballot(match);
             cnt += popc64(mm[j]);
@@ -525,6 +619,7 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
                 const uint32_t idx = run + popc64(mm[j] & lanemask_lt(lane));
                 LDSW(R.o_glp, idx) = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
                 LDSW(R.o_glw, idx) = wd[j];
+                LDSW(R.o_gli, idx) = info[j];
             }
             run += popc64(mm[j]);
         }
@@ -534,6 +629,196 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
     __syncthreads();
     if (tid == 0) { LDSW(R.o_ctl, RC_GLEN) = glen; LDSW(R.o_ctl, RC_NEXTP) = (M == 0u || next > last) ? last + 1 : next; }
     __syncthreads();
+}
+
+
+// Probability pass, one window: the spins of the sub-variables at its start (backward search for the last op on each, as
+// rvb_state_at) and the first batch of its ops (as rvb_gather, plus the info word of each) from ONE round of loads — the
+// look-back chunk and the first window chunk are requested together, then one barrier publishes both.  o_last must be all
+// zero on entry and is left all zero.  RC_GLEN / RC_NEXTP as rvb_gather (a first chunk that overflows the list is left to
+// rvb_gather's smaller steps: RC_GLEN 0, RC_NEXTP = from).
+template <int W, bool CL>
+__device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t from, uint32_t until,
+                                          uint32_t M, uint32_t nsub, uint32_t &gr) {
+    constexpr int NT = W * 64;
+    constexpr int UL = 4, UG = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
+    const uint32_t last = until < M ? until : M - 1; // inclusive
+    const uint32_t lo_b = from > (uint32_t)(UL * NT) ? from - (uint32_t)(UL * NT) : 0u; // look-back chunk [lo_b, from)
+    uint32_t wl[UL], wg[UG];
+#pragma unroll
+    for (int j = 0; j < UL; ++j) { const uint32_t p = lo_b + (uint32_t)(j * NT + tid); wl[j] = p < from ? ops[p] : 0u; }
+#pragma unroll
+    for (int j = 0; j < UG; ++j) { const uint32_t p = from + (uint32_t)(wave * 64 * UG + j * 64 + lane); wg[j] = (M != 0u && p <= last) ? ops[p] : 0u; }
+#pragma unroll
+    for (int j = 0; j < UL; ++j) {
+        if (wl[j]) {
+            const uint32_t p = lo_b + (uint32_t)(j * NT + tid);
+            const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wl[j]));
+            const uint32_t sa = v2s_get(R, d.a);
+            if (sa != 0xFFFFu) atomicMax(&LDSW(R.o_last, sa), ((p + 1u) << 1) | (sse_op_out(wl[j]) & 1u));
+            if (d.c != SSE_NO_VAR) {
+                const uint32_t sc = v2s_get(R, d.c);
+                if (sc != 0xFFFFu) atomicMax(&LDSW(R.o_last, sc), ((p + 1u) << 1) | ((sse_op_out(wl[j]) >> 1) & 1u));
+            }
+        }
+    }
+    uint32_t info[UG];
+    uint64_t mm[UG];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < UG; ++j) {
+        const Bd d = decode_bond<CL, W>(B, L, wg[j] ? sse_op_bond(wg[j]) : 0u);
+        const bool two = d.c != SSE_NO_VAR;
+        const uint32_t sa = v2s_get(R, d.a), sc = v2s_get(R, two ? d.c : d.a);
+        const bool ma = sa != 0xFFFFu, mc = two & (sc != 0xFFFFu);
+        info[j] = (ma ? sa : SSE_GI_NONE) | ((mc ? sc : SSE_GI_NONE) << 10) | (bd_kind(d) << SSE_GI_KIND_SHIFT) | (two ? SSE_GI_TWO : 0u);
+        mm[j] = sse_ballot((wg[j] != 0u) & (ma | mc));
+        cnt += popc64(mm[j]);
+    }
+    const int buf = gr & 1;
+    if (lane == 0) LDSI(L.o_tot, buf * W + wave) = cnt;
+    __syncthreads();
+    gr++;
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2); if (w2 < wave) wbase += t; total += t; }
+    const bool fits = total <= SSE_RVB_GCAP;
+    if (fits) {
+        uint32_t run = wbase;
+#pragma unroll
+        for (int j = 0; j < UG; ++j) {
+            if ((mm[j] >> lane) & 1ull) {
+                const uint32_t idx = run + popc64(mm[j] & lanemask_lt(lane));
+                LDSW(R.o_glp, idx) = from + (uint32_t)(wave * 64 * UG + j * 64 + lane);
+                LDSW(R.o_glw, idx) = wg[j];
+                LDSW(R.o_gli, idx) = info[j];
+            }
+            run += popc64(mm[j]);
+        }
+    }
+    if (lo_b > 0u) { // sub-variables without an op in the look-back chunk: keep searching
+        uint32_t missing = 0;
+        for (uint32_t s2 = tid; s2 < nsub; s2 += NT) missing |= (LDSW(R.o_last, s2) == 0u);
+        if (missing) LDSW(R.o_ctl, RC_SKIP) = 1u;
+    }
+    if (tid == 0) {
+        const uint32_t next = from + (uint32_t)(UG * NT);
+        LDSW(R.o_ctl, RC_GLEN) = fits ? total : 0u;
+        LDSW(R.o_ctl, RC_NEXTP) = M == 0u ? last + 1 : (!fits ? from : (next > last ? last + 1 : next));
+    }
+    __syncthreads();
+    uint32_t hi = lo_b;
+    while (LDSW(R.o_ctl, RC_SKIP)) { // (rare) the chunks before, one barrier round each, as rvb_state_at
+        __syncthreads();
+        if (tid == 0) LDSW(R.o_ctl, RC_SKIP) = 0u;
+        const uint32_t span = (uint32_t)(UL * NT);
+        const uint32_t lo = hi > span ? hi - span : 0u;
+#pragma unroll
+        for (int j = 0; j < UL; ++j) {
+            const uint32_t p = lo + (uint32_t)(j * NT + tid);
+            const uint32_t wd = p < hi ? ops[p] : 0u;
+            if (wd) {
+                const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
+                const uint32_t sa = v2s_get(R, d.a);
+                if (sa != 0xFFFFu) atomicMax(&LDSW(R.o_last, sa), ((p + 1u) << 1) | (sse_op_out(wd) & 1u));
+                if (d.c != SSE_NO_VAR) {
+                    const uint32_t sc = v2s_get(R, d.c);
+                    if (sc != 0xFFFFu) atomicMax(&LDSW(R.o_last, sc), ((p + 1u) << 1) | ((sse_op_out(wd) >> 1) & 1u));
+                }
+            }
+        }
+        __syncthreads();
+        hi = lo;
+        if (hi > 0u) {
+            uint32_t missing = 0;
+            for (uint32_t s2 = tid; s2 < nsub; s2 += NT) missing |= (LDSW(R.o_last, s2) == 0u);
+            if (missing) LDSW(R.o_ctl, RC_SKIP) = 1u;
+        }
+        __syncthreads();
+    }
+    for (uint32_t s2 = tid; s2 < nsub; s2 += NT) {
+        const uint32_t x = LDSW(R.o_last, s2);
+        const uint32_t v = LDSW(R.o_sub, s2);
+        const uint32_t bit = x ? (x & 1u) : ((LDSW(L.o_state, v >> 5) >> (v & 31)) & 1u);
+        LDSW(R.o_sfl, s2) = (LDSW(R.o_sfl, s2) & 3u) | (bit << 2);
+        LDSW(R.o_last, s2) = 0u;
+    }
+    __syncthreads();
+}
+
+// Probability pass over one batch of gathered ops (calculate_flip_prob, rvb.rs:649-946), by a whole wave.  Only the ops that
+// change something — off-diagonal ops and the cluster's own toggles — are visited one by one; the diagonal ops between two
+// of them are counted (those sitting on a boundary bond) and checked (longitudinal ops inside the cluster) 64 at a time
+// against the boundary set as it stands.  Returns true when the product has dropped to zero (`broke`).
+template <int W, bool CL>
+__device__ __forceinline__ bool rvb_replay_prob(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t glen, uint32_t ntog, uint32_t &next_tog,
+                                                uint32_t &nb, double &mult, BSetW &bs, int lane) {
+    const double EPS = 2.220446049250313e-16;
+    for (uint32_t base = 0; base < glen; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool valid = i < glen;
+        const uint32_t cnt = glen - base < 64u ? glen - base : 64u;
+        const uint32_t p = LDSW(R.o_glp, valid ? i : 0u), wd = LDSW(R.o_glw, valid ? i : 0u), info = LDSW(R.o_gli, valid ? i : 0u);
+        const uint32_t b = sse_op_bond(wd), in = sse_op_in(wd), out = sse_op_out(wd);
+        const uint32_t sa = info & SSE_GI_NONE, sc = (info >> 10) & SSE_GI_NONE, kind = (info >> SSE_GI_KIND_SHIFT) & 3u;
+        const bool two = (info & SSE_GI_TWO) != 0u, isedge = b < B.E, offdiag = in != out;
+        bool isb = false; // p is one of the toggles still ahead (both lists ascend)
+        for (uint32_t t = next_tog; t < ntog; ++t) isb |= p == LDSW(R.o_tog, t);
+        const uint64_t evm0 = sse_ballot(valid & (offdiag | isb));
+        uint32_t pos = 0;
+        for (;;) {
+            const bool inb = valid & isedge & ((uint32_t)LDSH(R.o_bix, (valid & isedge) ? b : 0u) != 0xFFFFu);
+            const uint64_t inbm = sse_ballot(inb);
+            const uint64_t ahead = ~lanemask_lt((int)pos) & (cnt < 64u ? lanemask_lt((int)cnt) : ~0ull);
+            const uint64_t ev = evm0 & ~inbm & ahead;
+            const uint32_t e = ev ? (uint32_t)__ffsll((long long)ev) - 1u : cnt;
+            const uint64_t seg = ahead & (e < 64u ? lanemask_lt((int)e) : ~0ull);
+            if (B.has_long) { // ising_ratio (qmc_ising.rs:722-735): a longitudinal op inside the cluster zeroes the product
+                const bool a_in = (sa != SSE_GI_NONE) && (LDSW(R.o_sfl, sa != SSE_GI_NONE ? sa : 0u) & 2u);
+                const bool c_in = (sc != SSE_GI_NONE) && (LDSW(R.o_sfl, sc != SSE_GI_NONE ? sc : 0u) & 2u);
+                const bool all_in = a_in && (!two || c_in);
+                const uint64_t lm = sse_ballot(valid & !inb & all_in & (kind == SSE_BOND_LONGITUDINAL)) & seg;
+                if (lm) {
+                    const uint32_t q = (uint32_t)__ffsll((long long)lm) - 1u;
+                    nb += (uint32_t)popc64(inbm & ahead & lanemask_lt((int)q));
+                    mult *= 0.0;
+                    if (mult < EPS) return true;
+                }
+            }
+            nb += (uint32_t)popc64(inbm & seg);
+            if (!ev) break;
+            // ---- the op at lane e changes the cluster or the spins ----
+            const uint32_t sae = (uint32_t)__builtin_amdgcn_readlane((int)sa, (int)e), sce = (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)e);
+            const uint32_t oute = (uint32_t)__builtin_amdgcn_readlane((int)out, (int)e), infoe = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)e);
+            const bool isbe = (sse_ballot(isb) >> e) & 1ull, offe = (sse_ballot(offdiag) >> e) & 1ull;
+            const bool twoe = (infoe & SSE_GI_TWO) != 0u;
+            const uint32_t kinde = (infoe >> SSE_GI_KIND_SHIFT) & 3u;
+            uint32_t fa = sae != SSE_GI_NONE ? LDSW(R.o_sfl, sae) : 0u, fc = sce != SSE_GI_NONE ? LDSW(R.o_sfl, sce) : 0u;
+            const bool all_in = (sae != SSE_GI_NONE) && (fa & 2u) && (!twoe || ((sce != SSE_GI_NONE) && (fc & 2u)));
+            if (isbe) { fa ^= 2u; next_tog++; }
+            if (offe) { fa = (fa & 3u) | ((oute & 1u) << 2); fc = (fc & 3u) | (((oute >> 1) & 1u) << 2); }
+            if (sae != SSE_GI_NONE) LDSW(R.o_sfl, sae) = fa;
+            if (offe && sce != SSE_GI_NONE) LDSW(R.o_sfl, sce) = fc;
+            SSE_WAVE_FENCE();
+            if (all_in) {
+                if (kinde == SSE_BOND_LONGITUDINAL) mult *= 0.0;
+                if (mult < EPS) return true;
+            }
+            if (!(nb == 0 || fabs(bs.tb - bs.ta) < EPS)) mult *= powi_sq(bs.ta / bs.tb, nb);
+            nb = 0;
+            if (mult < EPS) return true;
+            bool ok = true;
+            if (sae != SSE_GI_NONE) ok = rvb_update_bonds_w<CL, W>(B, L, R, LDSW(R.o_sub, sae), bs, false, lane);
+            if (ok && twoe && sce != SSE_GI_NONE) ok = rvb_update_bonds_w<CL, W>(B, L, R, LDSW(R.o_sub, sce), bs, false, lane);
+            if (!ok) { LDSW(R.o_ctl, RC_ERR) = 7u; return true; }
+            SSE_WAVE_FENCE();
+            pos = e + 1u;
+            if (pos >= cnt) break; // (also keeps the lane masks away from a shift by 64)
+        }
+    }
+    return false;
 }
 
 // get_propagated_substate_with_hint (fast_ops.rs:1027-1172): the spin of every sub-variable just before slot `from`
@@ -833,7 +1118,8 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     RvbLds R0;
     rvb_carve<W>(R0, L, B);
-    if (tid == 0) LDSW(R0.o_ctl, RC_ERR) = 0u;
+    if (tid == 0) { LDSW(R0.o_ctl, RC_ERR) = 0u; LDSW(R0.o_ctl, RC_SKIP) = 0u; LDSW(R0.o_ctl, RC_BROKE) = 0u; }
+    for (uint32_t i = tid; i < B.E; i += blockDim.x) LDSH(R0.o_bix, i) = (uint16_t)0xFFFFu;
     __syncthreads();
     SSE_STAMP_INIT; // diagnostic builds: 6 constants table, 7 growth, 8 states, 9 gathers, 10 replay (probability), 11 accept, 12 replay (mutation)
     const uint32_t C = rvb_find_constants<W, CL>(B, L, R0, r, M);
@@ -874,71 +1160,55 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
         g.k = LDSW(A.o_out, GO_K);
         RvbLds R = R0; // this attempt's lists
         R.o_sub = A.o_sub; R.o_sfl = A.o_sfl; R.o_tog = A.o_tog; R.o_togs = A.o_togs; R.o_wfrom = A.o_wfrom; R.o_wuntil = A.o_wuntil;
-        for (uint32_t s = tid; s < nsub; s += blockDim.x) LDSH(R0.o_v2s, LDSW(A.o_sub, s)) = (uint16_t)s;
+        for (uint32_t s = tid; s < nsub; s += blockDim.x) { LDSH(R0.o_v2s, LDSW(A.o_sub, s)) = (uint16_t)s; LDSW(R0.o_last, s) = 0u; }
         __syncthreads();
 
         // ================= phase B: calculate_flip_prob (rvb.rs:649-946) over the windows =================
-        double mult = 1.0;          // meaningful on the sequential lane
-        uint32_t nb = 0, next_tog = 0; // sequential lane
-        BSet bs;
-        bs.o_key = R.o_bk; bs.o_wb = R.o_bwb; bs.o_wa = R.o_bwa; bs.n = 0; bs.tb = 0.0; bs.ta = 0.0;
-        bool broke = false;
+        double mult = 1.0;             // wave 0
+        uint32_t nb = 0, next_tog = 0; // wave 0
+        BSetW bw;
+        bw.o_key = R.o_bk; bw.o_wb = R.o_bwb; bw.o_wa = R.o_bwa; bw.o_ix = R.o_bix; bw.n = 0; bw.tb = 0.0; bw.ta = 0.0;
         for (uint32_t wi = 0; wi < nwin; ++wi) {
             const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
-            rvb_state_at<W, CL>(B, L, R, r, from, nsub, false);
+            rvb_fetch<W, CL>(B, L, R, r, from, until, M, nsub, gr);
             SSE_STAMP(8);
-            if (tid == 0 && wi == 0 && from == 0 && !broke) {
-                if (!rvb_initial_bonds<CL, W>(B, L, R, nsub, bs, true)) LDSW(R.o_ctl, RC_ERR) = 7u;
-            }
-            uint32_t gp = from;
-            for (;;) {
-                SSE_STAMP(10);
-                rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
-                SSE_STAMP(9);
-                const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
-                gp = LDSW(R.o_ctl, RC_NEXTP);
-                if (tid == 0 && !broke && !LDSW(R.o_ctl, RC_ERR)) {
-                    for (uint32_t i = 0; i < glen; ++i) {
-                        const uint32_t p = LDSW(R.o_glp, i), wd = LDSW(R.o_glw, i);
-                        const uint32_t b = sse_op_bond(wd), in = sse_op_in(wd), out = sse_op_out(wd);
-                        const Bd d = decode_bond<CL, W>(B, L, b);
-                        const uint32_t sa = v2s_get(R, d.a), sc = d.c != SSE_NO_VAR ? v2s_get(R, d.c) : 0xFFFFu;
-                        const bool is_bound = next_tog < ntog && p == LDSW(R.o_tog, next_tog);
-                        const bool offdiag = in != out;
-                        const bool a_in = sa != 0xFFFFu && (LDSW(R.o_sfl, sa) & 2u);
-                        const bool c_in = sc != 0xFFFFu && (LDSW(R.o_sfl, sc) & 2u);
-                        const bool all_in = a_in && (d.c == SSE_NO_VAR || c_in);
-                        if (b < B.E && bs.find(b) >= 0) { nb++; continue; }
-                        if (is_bound) { LDSW(R.o_sfl, sa) ^= 2u; next_tog++; }
-                        if (offdiag) {
-                            if (sa != 0xFFFFu) LDSW(R.o_sfl, sa) = (LDSW(R.o_sfl, sa) & 3u) | ((out & 1u) << 2);
-                            if (sc != 0xFFFFu) LDSW(R.o_sfl, sc) = (LDSW(R.o_sfl, sc) & 3u) | (((out >> 1) & 1u) << 2);
-                        }
-                        if (all_in) { // ising_ratio (qmc_ising.rs:722-735): 0 for a longitudinal op, else 1
-                            if (bd_kind(d) == SSE_BOND_LONGITUDINAL) mult *= 0.0;
-                            if (mult < 2.220446049250313e-16) { broke = true; break; }
-                        }
-                        if (offdiag || is_bound) {
-                            if (!(nb == 0 || fabs(bs.tb - bs.ta) < 2.220446049250313e-16)) mult *= powi_sq(bs.ta / bs.tb, nb);
-                            nb = 0;
-                            if (mult < 2.220446049250313e-16) { broke = true; break; }
-                            bool ok = rvb_update_bonds<CL, W>(B, L, R, d.a, bs, true);
-                            if (ok && d.c != SSE_NO_VAR) ok = rvb_update_bonds<CL, W>(B, L, R, d.c, bs, true);
-                            if (!ok) { LDSW(R.o_ctl, RC_ERR) = 7u; break; }
-                        }
+            if (wave == 0 && wi == 0 && from == 0) { // set_initial_bonds (rvb.rs:617-645): the cluster's bonds to the outside, in order
+                bool ok = true;
+                for (uint32_t base = 0; base < nsub && ok; base += 64u) {
+                    const uint32_t s2 = base + (uint32_t)lane;
+                    uint64_t m = sse_ballot(s2 < nsub && (LDSW(R.o_sfl, s2 < nsub ? s2 : 0u) & 2u));
+                    while (m && ok) {
+                        const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
+                        m &= m - 1;
+                        ok = rvb_update_bonds_w<CL, W>(B, L, R, LDSW(R.o_sub, base + k), bw, true, lane);
                     }
                 }
-                if (M == 0u || gp > (until < M ? until : M - 1)) break;
+                if (!ok) LDSW(R.o_ctl, RC_ERR) = 7u;
             }
+            bool done = false;
+            for (;;) {
+                const uint32_t glen = LDSW(R.o_ctl, RC_GLEN), gp = LDSW(R.o_ctl, RC_NEXTP);
+                if (wave == 0 && !LDSW(R.o_ctl, RC_ERR)) {
+                    if (rvb_replay_prob<W, CL>(B, L, R, glen, ntog, next_tog, nb, mult, bw, lane)) LDSW(R.o_ctl, RC_BROKE) = 1u;
+                }
+                __syncthreads(); // the lists are free again; everybody learns whether the product is already zero
+                SSE_STAMP(10);
+                if (LDSW(R.o_ctl, RC_BROKE) || LDSW(R.o_ctl, RC_ERR)) { done = true; break; }
+                if (M == 0u || gp > (until < M ? until : M - 1)) break;
+                rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+                SSE_STAMP(9);
+            }
+            if (done) break;
         }
         // ================= phase C: accept (:241-246) =================
-        SSE_STAMP(10);
-        if (tid == 0) {
-            if (!(nb == 0 || fabs(bs.tb - bs.ta) < 2.220446049250313e-16)) mult *= powi_sq(bs.ta / bs.tb, nb);
+        if (wave == 0) {
+            if (!(nb == 0 || fabs(bw.tb - bw.ta) < 2.220446049250313e-16)) mult *= powi_sq(bw.ta / bw.tb, nb);
             const uint4 o = g.next();
             const bool accept = (mult >= 1.0) || (u01(o.x) < mult);
+            bw.clear(lane);
             LDSW(R.o_ctl, RC_ACCEPT) = accept ? 1u : 0u;
             LDSW(R.o_ctl, 9) = g.k;
+            LDSW(R.o_ctl, RC_BROKE) = 0u;
         }
         __syncthreads();
         SSE_STAMP(11);
@@ -949,7 +1219,8 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
             // cluster_state := starting state
             for (uint32_t s = tid; s < nsub; s += blockDim.x) { const uint32_t f = LDSW(R.o_sfl, s) & 1u; LDSW(R.o_sfl, s) = f | (f << 1); }
             __syncthreads();
-            bs.n = 0; bs.tb = 0.0; bs.ta = 0.0;
+            BSet bs;
+            bs.o_key = R.o_bk; bs.o_wb = R.o_bwb; bs.o_wa = R.o_bwa; bs.n = 0; bs.tb = 0.0; bs.ta = 0.0;
             uint32_t nt2 = 0;
             for (uint32_t wi = 0; wi < nwin; ++wi) {
                 const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);

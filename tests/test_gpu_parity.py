@@ -249,6 +249,24 @@ def test_rvb_fused_timesteps(oracle):
     assert g.verify().all()
 
 
+def test_rvb_config2_full_size(oracle):
+    """BASELINE configs[2] at full size (32x32, beta=16, ~10^5 slots): whole timesteps with the RVB sweep — batches of
+    attempts grown side by side, 64-op replay batches, look-back and window chunks of thousands of slots — op for op."""
+    edges = lat.two_d_ferro(32)
+    R = 3
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 1024, 1 << 18, 2718, R)
+    for it in range(2):
+        g.run(4, 16.0, sampling_freq=1, flags=8)
+        for rep in reps:
+            rep.timesteps(4, 16.0, 1, 8)
+        assert_same(g, reps, f"configs[2] rvb it={it}")
+    assert g.get_n().min() > 50000
+    acc = g.accumulators()
+    for r, rep in enumerate(reps):
+        assert np.array_equal(acc[r, :7], rep.accumulators()[:7])
+    assert g.verify().all()
+
+
 def test_large_lattice_64x64_runs_and_matches(oracle):
     """configs[3] geometry (64x64): edge table in LDS, union-find in HBM, many chunks per wave."""
     edges = lat.two_d_ferro(64)
