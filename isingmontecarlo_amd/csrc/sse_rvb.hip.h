@@ -23,7 +23,7 @@ namespace sse {
 #define SSE_RVB_MAXCL 72u      // cluster members (trailing_ones(u64)+1 <= 65)
 #define SSE_RVB_SETCAP 192u    // candidates in each weighted boundary set
 #define SSE_RVB_BONDCAP 288u   // boundary bonds tracked at once
-#define SSE_RVB_GCAP 1536u     // gathered ops per batch
+#define SSE_RVB_GCAP 768u      // gathered ops per batch (any size >= one wave's share of a gather step works)
 #define SSE_RVB_MAXWIN 80u     // time windows of one attempt
 
 struct RvbLds { // word offsets into lds_raw
@@ -123,61 +123,13 @@ __device__ __forceinline__ double powi_sq(double x, uint32_t n) {
     return r;
 }
 
-// ---- weighted candidate sets of the boundary manager (sequential lane only) ----
-struct WSet {
-    uint32_t o_key, o_var, o_w; // o_var == 0xFFFFFFFF: the variable is the key
-    uint32_t n;
-    double total;
-    __device__ __forceinline__ int find(uint32_t key) const {
-        for (uint32_t i = 0; i < n; ++i) if (LDSW(o_key, i) == key) return (int)i;
-        return -1;
-    }
-    // BondContainer::insert of (existing weight + w) (rvb.rs:1044-1045)
-    __device__ __forceinline__ bool add(uint32_t key, uint32_t var, double w) {
-        const int i = find(key);
-        if (i >= 0) {
-            const double old = ldsd(o_w, i), neww = old + w;
-            total += neww - old;
-            ldsd(o_w, i) = neww;
-            return true;
-        }
-        if (n >= SSE_RVB_SETCAP) return false;
-        LDSW(o_key, n) = key;
-        if (o_var != 0xFFFFFFFFu) LDSW(o_var, n) = var;
-        const double neww = 0.0 + w;
-        ldsd(o_w, n) = neww;
-        total += neww;
-        n++;
-        return true;
-    }
-    __device__ __forceinline__ void remove_at(uint32_t i) { // swap-remove (bondcontainer.rs:55-72)
-        const double w = ldsd(o_w, i);
-        const uint32_t last = n - 1;
-        LDSW(o_key, i) = LDSW(o_key, last);
-        if (o_var != 0xFFFFFFFFu) LDSW(o_var, i) = LDSW(o_var, last);
-        ldsd(o_w, i) = ldsd(o_w, last);
-        n--;
-        total -= w;
-        if (total < 0.0) total = 0.0;
-    }
-    __device__ __forceinline__ uint32_t pick(double u) const { // bondcontainer.rs:29-45
-        double p = u * total;
-        uint32_t i = 0;
-        while (i < n) {
-            p -= ldsd(o_w, i);
-            if (p <= 0.0) break;
-            i++;
-        }
-        return i < n ? i : n - 1;
-    }
-};
-
-
 // ---- wave-uniform execution -------------------------------------------------------------------------------------
 // The sequential rule of an attempt is run by ONE WAVE whose 64 lanes all hold the same scalars (the compiler keeps them in
 // SGPRs and branches on them with s_cbranch): the lanes differ only inside the searches, where lane i looks at entry i and a
 // ballot gives the answer — a linear search costs one LDS round trip instead of one per entry.  Stores write the same value
 // from every lane (one LDS write).
+// (x mod m) for x < 2m: the index arithmetic of the circular lists without an integer division
+__device__ __forceinline__ uint32_t wrap(uint32_t x, uint32_t m) { return x >= m ? x - m : x; }
 __device__ __forceinline__ double readlane_f64(double x, uint32_t l) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(x);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)l);
@@ -442,30 +394,7 @@ __device__ __forceinline__ bool rvb_update_bonds_w(const DevBatch &B, const Lds<
     return true;
 }
 
-// find_overlapping_starts (rvb.rs:1125-1158) over cps[fp0 .. fp0+Lf); calls f(index) for each overlapping segment
-template <typename F>
-__device__ __forceinline__ void rvb_overlaps(const RvbLds &R, uint32_t p_start, uint32_t p_end, uint32_t cutoff, uint32_t fp0, uint32_t Lf, F f) {
-    uint32_t bin = 0;
-    while (bin < Lf && LDSW(R.o_cps, fp0 + bin) < p_start) bin++;
-    const uint32_t prev = (bin + Lf - 1) % Lf;
-    const uint32_t lowest = LDSW(R.o_cps, fp0 + prev);
-    const uint32_t off_start = (p_start + cutoff - lowest) % cutoff, off_end = (p_end + cutoff - lowest) % cutoff;
-    for (uint32_t step = 0; step < Lf; ++step) {
-        const uint32_t ip = (prev + step) % Lf;
-        const uint32_t p = LDSW(R.o_cps, fp0 + ip);
-        const uint32_t check_start = (p + cutoff - lowest) % cutoff;
-        const uint32_t next_p = LDSW(R.o_cps, fp0 + (ip + 1) % Lf);
-        const uint32_t check_end = (next_p + cutoff - lowest) % cutoff;
-        const bool has_overlap_start = check_start < off_start && off_start < check_end;
-        const bool has_start_within = off_start < check_start && check_start < off_end;
-        const bool eq = (p_start == p_end) || (check_start == check_end);
-        if (!(eq || has_overlap_start || has_start_within)) break;
-        f(ip);
-    }
-}
-
-
-// find_overlapping_starts by a whole wave: the position lists are sorted, so the first entry >= p_start is a count, and the
+// find_overlapping_starts (rvb.rs:1125-1158) over cps[fp0 .. fp0+Lf) by a whole wave: the position lists are sorted, so the first entry >= p_start is a count, and the
 // run of overlapping segments ends at the first step whose test fails.  Calls f(index) for each overlapping segment, in order.
 template <typename F>
 __device__ __forceinline__ void rvb_overlaps_w(const RvbLds &R, uint32_t p_start, uint32_t p_end, uint32_t cutoff, uint32_t fp0, uint32_t Lf, int lane, F f) {
@@ -475,24 +404,24 @@ __device__ __forceinline__ void rvb_overlaps_w(const RvbLds &R, uint32_t p_start
         const uint32_t x = LDSW(R.o_cps, fp0 + (i < Lf ? i : 0u));
         bin += (uint32_t)popc64(sse_ballot((i < Lf) & (x < p_start)));
     }
-    const uint32_t prev = (bin + Lf - 1) % Lf;
+    const uint32_t prev = wrap(bin + Lf - 1, Lf);
     const uint32_t lowest = LDSW(R.o_cps, fp0 + prev);
-    const uint32_t off_start = (p_start + cutoff - lowest) % cutoff, off_end = (p_end + cutoff - lowest) % cutoff;
+    const uint32_t off_start = wrap(p_start + cutoff - lowest, cutoff), off_end = wrap(p_end + cutoff - lowest, cutoff); // (positions are below the cutoff)
     uint32_t count = Lf;
     for (uint32_t base = 0; base < Lf; base += 64u) {
         const uint32_t step = base + (uint32_t)lane;
         const bool in = step < Lf;
-        const uint32_t ip = (prev + (in ? step : 0u)) % Lf;
+        const uint32_t ip = wrap(prev + (in ? step : 0u), Lf);
         const uint32_t p = LDSW(R.o_cps, fp0 + ip);
-        const uint32_t next_p = LDSW(R.o_cps, fp0 + (ip + 1) % Lf);
-        const uint32_t check_start = (p + cutoff - lowest) % cutoff, check_end = (next_p + cutoff - lowest) % cutoff;
+        const uint32_t next_p = LDSW(R.o_cps, fp0 + wrap(ip + 1, Lf));
+        const uint32_t check_start = wrap(p + cutoff - lowest, cutoff), check_end = wrap(next_p + cutoff - lowest, cutoff);
         const bool has_overlap_start = check_start < off_start && off_start < check_end;
         const bool has_start_within = off_start < check_start && check_start < off_end;
         const bool eq = (p_start == p_end) || (check_start == check_end);
         const uint64_t stop = sse_ballot(in & !(eq || has_overlap_start || has_start_within));
         if (stop) { count = base + (uint32_t)__ffsll((long long)stop) - 1u; break; }
     }
-    for (uint32_t step = 0; step < count; ++step) f((prev + step) % Lf);
+    for (uint32_t step = 0; step < count; ++step) f(wrap(prev + step, Lf));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -568,69 +497,81 @@ __device__ __forceinline__ uint32_t rvb_find_constants(const DevBatch &B, const 
 }
 
 // Gather the ops of slots [gp, until] that touch a sub-variable, in p order, into the LDS list (one batch).
-// Returns through RC_GLEN / RC_NEXTP (slot to resume from, until+1 when the window is exhausted).
+// Returns through RC_GLEN / RC_NEXTP (slot to resume from, until+1 when the window is exhausted).  A step covers U*NT
+// slots, wave-major (a wave's lanes hold U*64 consecutive slots), and requests the next step's words before it works on
+// its own; a first step that alone overflows the list is cut at a wave boundary, so any list of >= U*64 entries is enough.
 template <int W, bool CL>
 __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t gp, uint32_t until,
                                            uint32_t M, uint32_t &gr) {
     constexpr int NT = W * 64;
     constexpr int U = 4;
+    static_assert(SSE_RVB_GCAP >= 64u * U, "the gathered-op list must hold one wave's share of a step");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t last = until < M ? until : M - 1; // inclusive
     uint32_t glen = 0, next = gp;
+    uint32_t wd[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint32_t p = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
+        wd[j] = (M != 0u && p <= last) ? ops[p] : 0u;
+    }
     while (M != 0u && next <= last) {
-        uint32_t wd[U], info[U];
+        uint32_t wn[U], info[U];
         uint64_t mm[U];
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const uint32_t p = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
-            wd[j] = p <= last ? ops[p] : 0u;
+            const uint32_t p = next + (uint32_t)(U * NT) + (uint32_t)(wave * 64 * U + j * 64 + lane);
+            wn[j] = p <= last ? ops[p] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            bool match = false;
-            info[j] = 0u;
-            if (wd[j]) {
-                const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
-                const bool two = d.c != SSE_NO_VAR;
-                const uint32_t sa = v2s_get(R, d.a), sc = two ? v2s_get(R, d.c) : 0xFFFFu;
-                match = sa != 0xFFFFu || sc != 0xFFFFu;
-                info[j] = (sa != 0xFFFFu ? sa : SSE_GI_NONE) | ((sc != 0xFFFFu ? sc : SSE_GI_NONE) << 10) | (bd_kind(d) << SSE_GI_KIND_SHIFT) | (two ? SSE_GI_TWO : 0u);
-            }
-            mm[j] = sse_ballot(match);
+            const Bd d = decode_bond<CL, W>(B, L, wd[j] ? sse_op_bond(wd[j]) : 0u);
+            const bool two = d.c != SSE_NO_VAR;
+            const uint32_t sa = v2s_get(R, d.a), sc = v2s_get(R, two ? d.c : d.a);
+            const bool ma = sa != 0xFFFFu, mc = two & (sc != 0xFFFFu);
+            info[j] = (ma ? sa : SSE_GI_NONE) | ((mc ? sc : SSE_GI_NONE) << 10) | (bd_kind(d) << SSE_GI_KIND_SHIFT) | (two ? SSE_GI_TWO : 0u);
+            mm[j] = sse_ballot((wd[j] != 0u) & (ma | mc));
             cnt += popc64(mm[j]);
         }
         const int buf = gr & 1;
         if (lane == 0) LDSI(L.o_tot, buf * W + wave) = cnt;
         __syncthreads();
         gr++;
-        uint32_t wbase = 0, total = 0;
+        uint32_t wbase = 0, total = 0, fit_waves = 0, fit_total = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2); if (w2 < wave) wbase += t; total += t; }
-        if (glen + total > SSE_RVB_GCAP) {
-            if (glen == 0) { if (tid == 0) LDSW(R.o_ctl, RC_ERR) = 5u; next = last + 1; }
-            break; // this chunk goes to the next batch
+        for (int w2 = 0; w2 < W; ++w2) {
+            const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2);
+            if (w2 < wave) wbase += t;
+            total += t;
+            if (fit_waves == (uint32_t)w2 && total <= SSE_RVB_GCAP) { fit_waves = (uint32_t)w2 + 1u; fit_total = total; } // longest prefix of waves that fits an empty list
         }
-        uint32_t run = glen + wbase;
+        const bool whole = glen + total <= SSE_RVB_GCAP;
+        if (!whole && glen != 0u) break; // this step opens the next batch
+        if (whole || (uint32_t)wave < fit_waves) {
+            uint32_t run = glen + wbase;
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            if ((mm[j] >> lane) & 1ull) {
-                const uint32_t idx = run + popc64(mm[j] & lanemask_lt(lane));
-                LDSW(R.o_glp, idx) = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
-                LDSW(R.o_glw, idx) = wd[j];
-                LDSW(R.o_gli, idx) = info[j];
+            for (int j = 0; j < U; ++j) {
+                if ((mm[j] >> lane) & 1ull) {
+                    const uint32_t idx = run + popc64(mm[j] & lanemask_lt(lane));
+                    LDSW(R.o_glp, idx) = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
+                    LDSW(R.o_glw, idx) = wd[j];
+                    LDSW(R.o_gli, idx) = info[j];
+                }
+                run += popc64(mm[j]);
             }
-            run += popc64(mm[j]);
         }
+        if (!whole) { glen = fit_total; next += fit_waves * (uint32_t)(64 * U); break; }
         glen += total;
         next += U * NT;
+#pragma unroll
+        for (int j = 0; j < U; ++j) wd[j] = wn[j];
     }
     __syncthreads();
     if (tid == 0) { LDSW(R.o_ctl, RC_GLEN) = glen; LDSW(R.o_ctl, RC_NEXTP) = (M == 0u || next > last) ? last + 1 : next; }
     __syncthreads();
 }
-
 
 // Probability pass, one window: the spins of the sub-variables at its start (backward search for the last op on each, as
 // rvb_state_at) and the first batch of its ops (as rvb_gather, plus the info word of each) from ONE round of loads — the
@@ -887,8 +828,8 @@ struct GrowArea {
     uint32_t cap_set, cap_cl, cap_sub, cap_win;
 };
 enum { GO_NSUB = 0, GO_NWIN = 1, GO_NTOG = 2, GO_K = 3, GO_ERR = 4 };
-#define SSE_RVB_SLOT_SET 48u
-#define SSE_RVB_SLOT_CL 16u
+#define SSE_RVB_SLOT_SET 40u
+#define SSE_RVB_SLOT_CL 12u
 #define SSE_RVB_SLOT_SUB (SSE_RVB_SLOT_CL + 2u * SSE_RVB_SLOT_SET)
 #define SSE_RVB_SLOT_WIN (SSE_RVB_SLOT_CL + 2u)
 #define SSE_RVB_SLOT_WORDS (7u * SSE_RVB_SLOT_SET + 6u * SSE_RVB_SLOT_CL + 3u * SSE_RVB_SLOT_SUB + 2u * SSE_RVB_SLOT_WIN + 8u)
@@ -982,8 +923,8 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
         const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
         if (flip != SSE_NO_VAR) {
             const uint32_t rel = flip - vs;
-            push_adj(v, (rel + vl - 1) % vl + vs, 1.0);
-            push_adj(v, (rel + 1) % vl + vs, 1.0);
+            push_adj(v, wrap(rel + vl - 1, vl) + vs, 1.0);
+            push_adj(v, wrap(rel + 1, vl) + vs, 1.0);
         }
         const uint32_t i1 = adj_begin(R, B, v + 1);
         for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
@@ -995,7 +936,7 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
             if (ol == 0) push_adj(ov, SSE_NO_VAR, weight);
             else if (flip != SSE_NO_VAR) {
                 const uint32_t rel = flip - vs;
-                const uint32_t finc = (rel + 1) % vl + vs;
+                const uint32_t finc = wrap(rel + 1, vl) + vs;
                 rvb_overlaps_w(R, LDSW(R.o_cps, flip), LDSW(R.o_cps, finc), M, os, ol, lane, [&](uint32_t ip) { push_adj(ov, ip + os, weight); });
             } else {
                 for (uint32_t pi = os; pi < os + ol; ++pi) push_adj(ov, pi, weight);
@@ -1133,6 +1074,9 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
     if (P > (uint32_t)W) P = (uint32_t)W;
     if (P > B.rvb_growers) P = B.rvb_growers;
     const uint32_t PB = P ? P : 1u; // attempts per batch
+#ifdef SSE_PHASE_TIMING
+    if (tid == 0) B.dbg[(size_t)r * 16 + 15] = P; // attempts grown side by side
+#endif
     const GrowArea big = grow_area_large(R0);
     bool stop = false;
 

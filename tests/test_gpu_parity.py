@@ -254,7 +254,7 @@ def test_rvb_config2_full_size(oracle):
     attempts grown side by side, 64-op replay batches, look-back and window chunks of thousands of slots — op for op."""
     edges = lat.two_d_ferro(32)
     R = 3
-    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 1024, 1 << 18, 2718, R)
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 150000, 1 << 18, 2718, R)
     for it in range(2):
         g.run(4, 16.0, sampling_freq=1, flags=8)
         for rep in reps:
