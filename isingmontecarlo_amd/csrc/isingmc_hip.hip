@@ -358,7 +358,8 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         b->last_W_off = Wo;
     };
     bool use_dev_off = false;
-    if (split && (A.domask & SSE_DO_RVB) && !b->W_off && b->W < 16) {
+    const bool rvb_only = (A.domask & ~SSE_DO_GROW) == SSE_DO_RVB;
+    if ((split || rvb_only) && (A.domask & SSE_DO_RVB) && !b->W_off && b->W < 16) {
         // RVB sweeps: the cooperative window scans of an attempt cover 4x more slots per step with 16 waves (the
         // sequential lane does not care); taken when the cluster tables of that geometry fit as well
         const LdsPlan p16 = plan_lds(b, 16);
@@ -377,7 +378,6 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             b->last_W_off = 16;
         }
     }
-    const bool rvb_only = (A.domask & ~SSE_DO_GROW) == SSE_DO_RVB;
     if (rvb_only) lc.passes = SSE_PASSES_RVB;   // the RVB sweep alone: its own kernel (no scratch spills, unlike the all-passes kernel)
     else if (loop_only) lc.passes = SSE_PASSES_DIAG; // a lone directed loop uses the small launch geometry too
     else if (!(A.domask & (SSE_DO_DIAG | SSE_DO_RVB | SSE_DO_LOOP)) || (split && !(A.domask & SSE_DO_RVB))) {

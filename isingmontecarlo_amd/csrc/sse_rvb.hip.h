@@ -19,6 +19,9 @@
 
 namespace sse {
 
+#ifndef SSE_RVB_ADJ_LDS
+#define SSE_RVB_ADJ_LDS 0 // 1: stage the adjacency lists in LDS (faster reads, fewer growth areas)
+#endif
 #define SSE_RVB_MAXSUB 512u    // sub-variables (cluster + boundary) of one attempt
 #define SSE_RVB_MAXCL 72u      // cluster members (trailing_ones(u64)+1 <= 65)
 #define SSE_RVB_SETCAP 192u    // candidates in each weighted boundary set
@@ -60,7 +63,7 @@ __device__ __forceinline__ double &ldsd(uint32_t off, uint32_t i) { return reint
 
 // words of RVB scratch in front of the constant-op table (mirrors rvb_carve; used by the host to size LDS)
 __host__ __device__ inline uint32_t rvb_fixed_words(uint32_t N, uint32_t E) {
-    const uint32_t adj = (N < 65535u && E < 65535u) ? (N + 2) / 2 + E : 0u;
+    const uint32_t adj = SSE_RVB_ADJ_LDS && (N < 65535u && E < 65535u) ? (N + 2) / 2 + E : 0u;
     return 1u + 4 * SSE_RVB_SETCAP + 4 * SSE_RVB_BONDCAP + (N + 1) + N + (N + 1) / 2 + adj + 3 * SSE_RVB_MAXSUB +
            6 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 3 * SSE_RVB_GCAP + (E + 1) / 2 + 16 + 8;
 }
@@ -75,7 +78,7 @@ __device__ __forceinline__ void rvb_carve(RvbLds &R, const Lds<W> &L, const DevB
     R.o_vstart = base; base += B.N + 1;
     R.o_zero = base; base += B.N;
     R.o_v2s = base; base += (B.N + 1) / 2;
-    R.adj_lds = (B.N < 65535u && B.E < 65535u) ? 1u : 0u;
+    R.adj_lds = SSE_RVB_ADJ_LDS && (B.N < 65535u && B.E < 65535u) ? 1u : 0u;
     R.o_adjs = base; base += R.adj_lds ? (B.N + 2) / 2 : 0u;
     R.o_adj = base; base += R.adj_lds ? B.E : 0u; // 2E u16
     R.o_sub = base; base += SSE_RVB_MAXSUB;
@@ -504,7 +507,7 @@ template <int W, bool CL>
 __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t gp, uint32_t until,
                                            uint32_t M, uint32_t &gr) {
     constexpr int NT = W * 64;
-    constexpr int U = 4;
+    constexpr int U = 8;
     static_assert(SSE_RVB_GCAP >= 64u * U, "the gathered-op list must hold one wave's share of a step");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
@@ -1075,7 +1078,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
     if (P > B.rvb_growers) P = B.rvb_growers;
     const uint32_t PB = P ? P : 1u; // attempts per batch
 #ifdef SSE_PHASE_TIMING
-    if (tid == 0) B.dbg[(size_t)r * 16 + 15] = P; // attempts grown side by side
+    if (tid == 0) { B.dbg[(size_t)r * 16 + 15] = P; B.dbg[(size_t)r * 16 + 14] = B.lds_words; B.dbg[(size_t)r * 16 + 13] = C; B.dbg[(size_t)r * 16 + 5] = R0.o_cps; } // attempts grown side by side
 #endif
     const GrowArea big = grow_area_large(R0);
     bool stop = false;
