@@ -154,6 +154,12 @@ struct WSetW {
     uint32_t o_key, o_var, o_w; // o_var == 0xFFFFFFFF: the variable is the key
     uint32_t n, cap;
     double total;
+    __device__ __forceinline__ void init(uint32_t ok, uint32_t ov, uint32_t ow, uint32_t c) { o_key = ok; o_var = ov; o_w = ow; n = 0; cap = c; total = 0.0; }
+    __device__ __forceinline__ uint32_t key_at(uint32_t i) const { return LDSW(o_key, i); }
+    __device__ __forceinline__ uint32_t var_at(uint32_t i) const { return LDSW(o_var != 0xFFFFFFFFu ? o_var : o_key, i); }
+    __device__ __forceinline__ void dump_vars(uint32_t o_dst, uint32_t at, int lane) const { // dst[at + i] = variable of entry i
+        for (uint32_t base = 0; base < n; base += 64u) { const uint32_t i = base + (uint32_t)lane; if (i < n) LDSW(o_dst, at + i) = var_at(i); }
+    }
     __device__ __forceinline__ bool add(uint32_t key, uint32_t var, double w, int lane) { // BondContainer::insert of (existing weight + w) (rvb.rs:1044-1045)
         const int i = wv_find(o_key, n, key, lane);
         if (i >= 0) {
@@ -196,6 +202,91 @@ struct WSetW {
         return n - 1;
     }
 };
+
+// The same set for at most 64 entries with the keys (and variables) held in registers, entry i in lane i: a lookup is a
+// compare and a ballot, no LDS round trip; only the weights stay in LDS (read when an entry is drawn or changed).
+struct WSetR {
+    uint32_t keyv, varv, lane_; // lane_: this lane's index (writes to "entry i" are selects on it)
+    uint32_t o_w;
+    bool has_var;
+    uint32_t n, cap;
+    double total;
+    __device__ __forceinline__ void init(uint32_t, uint32_t ov, uint32_t ow, uint32_t c) { keyv = 0u; varv = 0u; lane_ = __lane_id(); has_var = ov != 0xFFFFFFFFu; o_w = ow; n = 0; cap = c < 64u ? c : 64u; total = 0.0; }
+    __device__ __forceinline__ uint32_t key_at(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)keyv, (int)i); }
+    __device__ __forceinline__ uint32_t var_at(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)(has_var ? varv : keyv), (int)i); }
+    __device__ __forceinline__ void dump_vars(uint32_t o_dst, uint32_t at, int lane) const { if ((uint32_t)lane < n) LDSW(o_dst, at + (uint32_t)lane) = has_var ? varv : keyv; }
+    __device__ __forceinline__ bool add(uint32_t key, uint32_t var, double w, int lane) {
+        const uint64_t m = sse_ballot(((uint32_t)lane < n) & (keyv == key));
+        if (m) {
+            const uint32_t i = (uint32_t)__ffsll((long long)m) - 1u;
+            const double old = ldsd(o_w, i), neww = old + w;
+            total += neww - old;
+            ldsd(o_w, i) = neww;
+            return true;
+        }
+        if (n >= cap) return false;
+        keyv = (lane_ == n ? key : keyv);
+        if (has_var) varv = (lane_ == n ? var : varv);
+        const double neww = 0.0 + w;
+        ldsd(o_w, n) = neww;
+        total += neww;
+        n++;
+        return true;
+    }
+    __device__ __forceinline__ void remove_at(uint32_t i) {
+        const uint32_t last = n - 1;
+        const double w = ldsd(o_w, i), wl = ldsd(o_w, last);
+        { const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)keyv, (int)last); keyv = lane_ == i ? kl : keyv; }
+        if (has_var) { const uint32_t vl = (uint32_t)__builtin_amdgcn_readlane((int)varv, (int)last); varv = lane_ == i ? vl : varv; }
+        ldsd(o_w, i) = wl;
+        n--;
+        total -= w;
+        if (total < 0.0) total = 0.0;
+    }
+    __device__ __forceinline__ uint32_t pick(double u, int lane) const {
+        double p = u * total;
+        const double w = ldsd(o_w, (uint32_t)lane < n ? (uint32_t)lane : 0u);
+        for (uint32_t j = 0; j < n; ++j) {
+            p -= readlane_f64(w, j);
+            if (p <= 0.0) return j;
+        }
+        return n - 1;
+    }
+};
+// members of the growing cluster (variable, flip index or SSE_NO_VAR), in LDS or in registers
+struct ClusterL {
+    uint32_t o_v, o_f, n, cap;
+    __device__ __forceinline__ void init(uint32_t ov, uint32_t of, uint32_t c) { o_v = ov; o_f = of; n = 0; cap = c; }
+    __device__ __forceinline__ void push(uint32_t v, uint32_t f) { LDSW(o_v, n) = v; LDSW(o_f, n) = f; n++; }
+    __device__ __forceinline__ uint32_t v_at(uint32_t i) const { return LDSW(o_v, i); }
+    __device__ __forceinline__ uint32_t f_at(uint32_t i) const { return LDSW(o_f, i); }
+    __device__ __forceinline__ bool contains(uint32_t var, uint32_t pos, int lane) const { // popped flags of the boundary manager (:1038-1043)
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane, ii = i < n ? i : 0u;
+            const uint32_t cf = LDSW(o_f, ii), cv = LDSW(o_v, ii);
+            const bool hit = pos != SSE_NO_VAR ? cf == pos : (cf == SSE_NO_VAR && cv == var);
+            if (sse_ballot((i < n) & hit)) return true;
+        }
+        return false;
+    }
+    __device__ __forceinline__ void dump_vars(uint32_t o_dst, uint32_t at, int lane) const {
+        for (uint32_t base = 0; base < n; base += 64u) { const uint32_t i = base + (uint32_t)lane; if (i < n) LDSW(o_dst, at + i) = LDSW(o_v, i); }
+    }
+};
+struct ClusterR {
+    uint32_t vv, fv, lane_, n, cap;
+    __device__ __forceinline__ void init(uint32_t, uint32_t, uint32_t c) { vv = 0u; fv = 0u; lane_ = __lane_id(); n = 0; cap = c < 64u ? c : 64u; }
+    __device__ __forceinline__ void push(uint32_t v, uint32_t f) { vv = (lane_ == n ? v : vv); fv = (lane_ == n ? f : fv); n++; }
+    __device__ __forceinline__ uint32_t v_at(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)vv, (int)i); }
+    __device__ __forceinline__ uint32_t f_at(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)i); }
+    __device__ __forceinline__ bool contains(uint32_t var, uint32_t pos, int lane) const {
+        const bool hit = pos != SSE_NO_VAR ? fv == pos : (fv == SSE_NO_VAR && vv == var);
+        return sse_ballot(((uint32_t)lane < n) & hit) != 0ull;
+    }
+    __device__ __forceinline__ void dump_vars(uint32_t o_dst, uint32_t at, int lane) const { if ((uint32_t)lane < n) LDSW(o_dst, at + (uint32_t)lane) = vv; }
+};
+template <bool REG> struct GrowTypes { typedef WSetW Set; typedef ClusterL Cluster; };
+template <> struct GrowTypes<true> { typedef WSetR Set; typedef ClusterR Cluster; };
 
 // ---- boundary-bond sets: one key list, weights before / after the flip ----
 struct BSet {
@@ -831,21 +922,17 @@ struct GrowArea {
     uint32_t cap_set, cap_cl, cap_sub, cap_win;
 };
 enum { GO_NSUB = 0, GO_NWIN = 1, GO_NTOG = 2, GO_K = 3, GO_ERR = 4 };
-#define SSE_RVB_SLOT_SET 40u
-#define SSE_RVB_SLOT_CL 12u
+#define SSE_RVB_SLOT_SET 48u // (<= 64: the keys of a small area live in registers)
+#define SSE_RVB_SLOT_CL 16u
 #define SSE_RVB_SLOT_SUB (SSE_RVB_SLOT_CL + 2u * SSE_RVB_SLOT_SET)
 #define SSE_RVB_SLOT_WIN (SSE_RVB_SLOT_CL + 2u)
-#define SSE_RVB_SLOT_WORDS (7u * SSE_RVB_SLOT_SET + 6u * SSE_RVB_SLOT_CL + 3u * SSE_RVB_SLOT_SUB + 2u * SSE_RVB_SLOT_WIN + 8u)
+#define SSE_RVB_SLOT_WORDS (4u * SSE_RVB_SLOT_SET + 4u * SSE_RVB_SLOT_CL + 3u * SSE_RVB_SLOT_SUB + 2u * SSE_RVB_SLOT_WIN + 8u)
 __device__ __forceinline__ GrowArea grow_area_small(uint32_t base) { // base even (doubles)
     GrowArea A;
     A.cap_set = SSE_RVB_SLOT_SET; A.cap_cl = SSE_RVB_SLOT_CL; A.cap_sub = SSE_RVB_SLOT_SUB; A.cap_win = SSE_RVB_SLOT_WIN;
     A.o_bfw = base; base += 2 * A.cap_set;
     A.o_bnw = base; base += 2 * A.cap_set;
-    A.o_bfk = base; base += A.cap_set;
-    A.o_bfv = base; base += A.cap_set;
-    A.o_bnk = base; base += A.cap_set;
-    A.o_clv = base; base += A.cap_cl;
-    A.o_clf = base; base += A.cap_cl;
+    A.o_bfk = A.o_bfv = A.o_bnk = A.o_clv = A.o_clf = 0u; // in registers (rvb_grow<.., REG = true>)
     A.o_tog = base; base += 2 * A.cap_cl;
     A.o_togs = base; base += 2 * A.cap_cl;
     A.o_sub = base; base += A.cap_sub;
@@ -867,7 +954,7 @@ __device__ __forceinline__ GrowArea grow_area_large(const RvbLds &R) {
 }
 
 // start, cluster growth, sub-variables, windows of one attempt (rvb.rs:88-232, :1054-1123); run by a whole wave, uniform
-template <int W, bool CL>
+template <int W, bool CL, bool REG>
 __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, const RvbLds &R, const GrowArea &A, RvbDraw g, uint32_t C, uint32_t nzero,
                                          uint32_t M, int lane) {
     const uint32_t N = B.N;
@@ -891,21 +978,13 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
     unsigned long long bits = (unsigned long long)o.x | ((unsigned long long)o.y << 32);
     uint32_t csize = 1;
     while ((bits & 1ull) && csize <= 64) { csize++; bits >>= 1; }
-    WSetW bf, bn;
-    bf.o_key = A.o_bfk; bf.o_var = A.o_bfv; bf.o_w = A.o_bfw; bf.n = 0; bf.total = 0.0; bf.cap = A.cap_set;
-    bn.o_key = A.o_bnk; bn.o_var = 0xFFFFFFFFu; bn.o_w = A.o_bnw; bn.n = 0; bn.total = 0.0; bn.cap = A.cap_set;
-    uint32_t ncl = 0;
-    auto in_cluster = [&](uint32_t var, uint32_t pos) -> bool { // popped flags of the boundary manager (:1038-1043)
-        for (uint32_t base = 0; base < ncl; base += 64u) {
-            const uint32_t i = base + (uint32_t)lane, ii = i < ncl ? i : 0u;
-            const uint32_t cf = LDSW(A.o_clf, ii), cv = LDSW(A.o_clv, ii);
-            const bool hit = pos != SSE_NO_VAR ? cf == pos : (cf == SSE_NO_VAR && cv == var);
-            if (sse_ballot((i < ncl) & hit)) return true;
-        }
-        return false;
-    };
+    typename GrowTypes<REG>::Set bf, bn; // REG: keys in registers (small areas, <= 64 entries), else in LDS
+    typename GrowTypes<REG>::Cluster cl;
+    bf.init(A.o_bfk, A.o_bfv, A.o_bfw, A.cap_set);
+    bn.init(A.o_bnk, 0xFFFFFFFFu, A.o_bnw, A.cap_set);
+    cl.init(A.o_clv, A.o_clf, A.cap_cl);
     auto push_adj = [&](uint32_t var, uint32_t pos, double w) {
-        if (in_cluster(var, pos)) return;
+        if (cl.contains(var, pos, lane)) return;
         const bool ok = pos != SSE_NO_VAR ? bf.add(pos, var, w, lane) : bn.add(var, var, w, lane);
         if (!ok) lerr = 7u;
     };
@@ -919,10 +998,10 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
         if (bn.n == 0) pick_flips = true;
         o = g.next();
         uint32_t v, flip;
-        if (pick_flips) { const uint32_t idx = bf.pick(u01(o.x), lane); v = LDSW(bf.o_var, idx); flip = LDSW(bf.o_key, idx); bf.remove_at(idx); }
-        else { const uint32_t idx = bn.pick(u01(o.x), lane); v = LDSW(bn.o_key, idx); flip = SSE_NO_VAR; bn.remove_at(idx); }
-        if (ncl >= A.cap_cl) { lerr = 7u; break; }
-        LDSW(A.o_clv, ncl) = v; LDSW(A.o_clf, ncl) = flip; ncl++;
+        if (pick_flips) { const uint32_t idx = bf.pick(u01(o.x), lane); v = bf.var_at(idx); flip = bf.key_at(idx); bf.remove_at(idx); }
+        else { const uint32_t idx = bn.pick(u01(o.x), lane); v = bn.key_at(idx); flip = SSE_NO_VAR; bn.remove_at(idx); }
+        if (cl.n >= cl.cap) { lerr = 7u; break; }
+        cl.push(v, flip);
         const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
         if (flip != SSE_NO_VAR) {
             const uint32_t rel = flip - vs;
@@ -950,12 +1029,10 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
     // ---- sub-variables: sorted union of cluster and remaining boundary variables (:155-172) ----
     // candidates -> o_last; an entry that repeats an earlier one is marked, the others rank themselves among the
     // unmarked ones (lane per candidate, the comparison partner is broadcast from LDS)
+    const uint32_t ncl = cl.n;
     const uint32_t nc = lerr ? 0u : ncl + bf.n + bn.n;
     if (nc > A.cap_sub) lerr = 7u;
-    for (uint32_t base = 0; base < nc && !lerr; base += 64u) {
-        const uint32_t i = base + (uint32_t)lane;
-        if (i < nc) LDSW(A.o_tmp, i) = i < ncl ? LDSW(A.o_clv, i) : (i < ncl + bf.n ? LDSW(bf.o_var, i - ncl) : LDSW(bn.o_key, i - ncl - bf.n));
-    }
+    if (!lerr) { cl.dump_vars(A.o_tmp, 0u, lane); bf.dump_vars(A.o_tmp, ncl, lane); bn.dump_vars(A.o_tmp, ncl + bf.n, lane); }
     SSE_WAVE_FENCE();
     uint32_t nsub = 0;
     if (!lerr) {
@@ -983,7 +1060,7 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
     // ---- starting state and toggle positions (:174-196), sort, remove_doubles (:230-231) ----
     uint32_t ntog = 0;
     for (uint32_t i = 0; i < ncl && !lerr; ++i) {
-        const uint32_t v = LDSW(A.o_clv, i), fi = LDSW(A.o_clf, i);
+        const uint32_t v = cl.v_at(i), fi = cl.f_at(i);
         const uint32_t sv = (uint32_t)wv_find(A.o_sub, nsub, v, lane); // the list is this attempt's own: the shared var -> sub table is filled when its turn comes
         if (fi != SSE_NO_VAR) {
             const uint32_t vs = LDSW(R.o_vstart, v), vl = LDSW(R.o_vstart, v + 1) - vs;
@@ -1087,7 +1164,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
     if (P && (uint32_t)wave < P && a0 + (uint32_t)wave < updates) {
         RvbDraw g;
         g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.rid ? B.rid[r] : B.replica_offset + r; g.epoch_lo = (uint32_t)epoch; g.attempt = a0 + (uint32_t)wave; g.k = 0;
-        rvb_grow<W, CL>(B, L, R0, grow_area_small(slots0 + (uint32_t)wave * SSE_RVB_SLOT_WORDS), g, C, nzero, M, lane);
+        rvb_grow<W, CL, true>(B, L, R0, grow_area_small(slots0 + (uint32_t)wave * SSE_RVB_SLOT_WORDS), g, C, nzero, M, lane);
     }
     __syncthreads();
     SSE_STAMP(7);
@@ -1098,7 +1175,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
         GrowArea A = P ? grow_area_small(slots0 + aj * SSE_RVB_SLOT_WORDS) : big;
         if (!P || LDSW(A.o_out, GO_ERR)) { // no room for small areas, or this cluster outgrew its own: the large area
             A = big;
-            if (wave == 0) rvb_grow<W, CL>(B, L, R0, big, g, C, nzero, M, lane);
+            if (wave == 0) rvb_grow<W, CL, false>(B, L, R0, big, g, C, nzero, M, lane);
             __syncthreads();
             SSE_STAMP(7);
         }
