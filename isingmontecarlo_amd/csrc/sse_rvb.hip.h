@@ -1008,20 +1008,29 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
             push_adj(v, wrap(rel + vl - 1, vl) + vs, 1.0);
             push_adj(v, wrap(rel + 1, vl) + vs, 1.0);
         }
-        const uint32_t i1 = adj_begin(R, B, v + 1);
-        for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
-            const uint32_t b = adj_at(R, B, i);
-            const Bd d = decode_bond<CL, W>(B, L, b);
-            const double weight = d.w * 0.5; // bond_mag = |J| (qmc_ising.rs:633-635)
-            const uint32_t ov = d.a == v ? d.c : d.a;
-            const uint32_t os = LDSW(R.o_vstart, ov), ol = LDSW(R.o_vstart, ov + 1) - os;
-            if (ol == 0) push_adj(ov, SSE_NO_VAR, weight);
-            else if (flip != SSE_NO_VAR) {
-                const uint32_t rel = flip - vs;
-                const uint32_t finc = wrap(rel + 1, vl) + vs;
-                rvb_overlaps_w(R, LDSW(R.o_cps, flip), LDSW(R.o_cps, finc), M, os, ol, lane, [&](uint32_t ip) { push_adj(ov, ip + os, weight); });
-            } else {
-                for (uint32_t pi = os; pi < os + ol; ++pi) push_adj(ov, pi, weight);
+        // the neighbours of v: lane k fetches bond k of its adjacency list and the other end's range of the position table
+        // (one round of loads for all of them), then they are taken in list order
+        const uint32_t i0 = adj_begin(R, B, v), i1 = adj_begin(R, B, v + 1);
+        for (uint32_t nbase = i0; nbase < i1; nbase += 64u) {
+            const uint32_t ni = nbase + (uint32_t)lane;
+            const bool nin = ni < i1;
+            const Bd dl = decode_bond<CL, W>(B, L, adj_at(R, B, nin ? ni : i0));
+            const uint32_t ovl = dl.a == v ? dl.c : dl.a;
+            const uint32_t osl = LDSW(R.o_vstart, ovl), oll = LDSW(R.o_vstart, ovl + 1) - osl;
+            const double wl = dl.w * 0.5; // bond_mag = |J| (qmc_ising.rs:633-635)
+            const uint32_t ncnt = i1 - nbase < 64u ? i1 - nbase : 64u;
+            for (uint32_t k = 0; k < ncnt; ++k) {
+                const uint32_t ov = (uint32_t)__builtin_amdgcn_readlane((int)ovl, (int)k), os = (uint32_t)__builtin_amdgcn_readlane((int)osl, (int)k);
+                const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)oll, (int)k);
+                const double weight = readlane_f64(wl, k);
+                if (ol == 0) push_adj(ov, SSE_NO_VAR, weight);
+                else if (flip != SSE_NO_VAR) {
+                    const uint32_t rel = flip - vs;
+                    const uint32_t finc = wrap(rel + 1, vl) + vs;
+                    rvb_overlaps_w(R, LDSW(R.o_cps, flip), LDSW(R.o_cps, finc), M, os, ol, lane, [&](uint32_t ip) { push_adj(ov, ip + os, weight); });
+                } else {
+                    for (uint32_t pi = os; pi < os + ol; ++pi) push_adj(ov, pi, weight);
+                }
             }
         }
         left--;
