@@ -681,6 +681,7 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t last = until < M ? until : M - 1; // inclusive
     const uint32_t lo_b = from > (uint32_t)(UL * NT) ? from - (uint32_t)(UL * NT) : 0u; // look-back chunk [lo_b, from)
+    SSE_STAMP_INIT; // diagnostic builds: 0 loads + matching, 1 compaction, 2 longer look-back, 3 states
     uint32_t wl[UL], wg[UG];
 #pragma unroll
     for (int j = 0; j < UL; ++j) { const uint32_t p = lo_b + (uint32_t)(j * NT + tid); wl[j] = p < from ? ops[p] : 0u; }
@@ -715,6 +716,7 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
     const int buf = gr & 1;
     if (lane == 0) LDSI(L.o_tot, buf * W + wave) = cnt;
     __syncthreads();
+    SSE_STAMP(0);
     gr++;
     uint32_t wbase = 0, total = 0;
 #pragma unroll
@@ -744,6 +746,7 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
         LDSW(R.o_ctl, RC_NEXTP) = M == 0u ? last + 1 : (!fits ? from : (next > last ? last + 1 : next));
     }
     __syncthreads();
+    SSE_STAMP(1);
     uint32_t hi = lo_b;
     while (LDSW(R.o_ctl, RC_SKIP)) { // (rare) the chunks before, one barrier round each, as rvb_state_at
         __syncthreads();
@@ -773,6 +776,7 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
         }
         __syncthreads();
     }
+    SSE_STAMP(2);
     for (uint32_t s2 = tid; s2 < nsub; s2 += NT) {
         const uint32_t x = LDSW(R.o_last, s2);
         const uint32_t v = LDSW(R.o_sub, s2);
@@ -781,6 +785,7 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
         LDSW(R.o_last, s2) = 0u;
     }
     __syncthreads();
+    SSE_STAMP(3);
 }
 
 // Probability pass over one batch of gathered ops (calculate_flip_prob, rvb.rs:649-946), by a whole wave.  Only the ops that

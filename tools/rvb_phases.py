@@ -27,4 +27,5 @@ if tk.any():
     g.single_rvb_sweep()
     t = g.debug_phase_ticks().astype(float).mean(axis=0) * 10e-3
     names = {6: "constants table", 7: "growth (sequential)", 8: "states at window starts", 9: "gathers", 10: "replay: probability", 11: "accept", 12: "replay: mutation"}
+    print("inside the fetch, us: loads + matching %.0f, compaction %.0f, longer look-back %.0f, states %.0f" % tuple(t[:4]))
     print("per replica, us: " + ", ".join(f"{names[k]} {t[k]:.0f}" for k in sorted(names)) + f"; sum {sum(t[k] for k in names):.0f}; growers {t[15] / 10e-3:.0f}, LDS words {t[14] / 10e-3:.0f}, constants {t[13] / 10e-3:.0f}, table at {t[5] / 10e-3:.0f}")
