@@ -8,6 +8,9 @@ RAW, OUT = os.path.join(ROOT, "gpurun_out", "profiles_raw"), os.path.join(ROOT, 
 # (gpurun merges every call's output: pick this round's stats file, the one that saw the trimmed diagonal kernel)
 stats = [f for f in sorted(glob.glob(os.path.join(RAW, "stats", "*", "*_kernel_stats.csv"))) if "sweep_fast_kernel" in open(f).read()]
 shutil.copy(stats[-1], os.path.join(OUT, R + "_kernel_stats.csv"))
+stats_rvb = sorted(glob.glob(os.path.join(RAW, "stats_rvb", "*", "*_kernel_stats.csv")))
+if stats_rvb:
+    shutil.copy(stats_rvb[-1], os.path.join(OUT, R + "_kernel_stats_config2_rvb.csv"))
 for f in glob.glob(os.path.join(RAW, R + "_*.json")) + glob.glob(os.path.join(RAW, R + "_*.txt")):
     shutil.copy(f, OUT)
 # the timed kernels: PHASE = 0 symbols (PHASE = 1 is the identical code under its data-preparation name)

@@ -16,6 +16,8 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUS
 python bench.py --pmj3d 32 --beta 4 --replicas 512 --equilibrate 60 --steps 10 --warmup 2 --no-cpu-baseline > $O/${R}_bench_pmj3d32.json
 python bench.py --pmj3d 16 --beta 4 --replicas 512 --equilibrate 60 --steps 20 --warmup 3 --no-cpu-baseline > $O/${R}_bench_pmj3d16.json
 python bench.py --rvb --steps 4 --warmup 1 --equilibrate 60 > $O/${R}_bench_config2_rvb.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_rvb -- python3 bench.py --rvb --steps 4 --warmup 1 --equilibrate 60 --no-cpu-baseline > /dev/null
+python tools/rvb_phases.py > $O/${R}_rvb_sweep.txt
 python tools/bench_tempering.py > $O/${R}_bench_tempering_64x64.json
 python tools/bench_tempering.py --window 2.0 1.05 > $O/${R}_bench_tempering_64x64_window.json
 python tools/pass_split.py > $O/${R}_pass_split.txt

@@ -13,12 +13,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--L", type=int, default=32); ap.add_argument("--beta", type=float, default=16.0)
 ap.add_argument("--replicas", type=int, default=1024); ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--equilibrate", type=int, default=60); ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--k", type=int, default=0); ap.add_argument("--nolds", action="store_true")
+ap.add_argument("--woff", type=int, default=0); ap.add_argument("--k", type=int, default=0); ap.add_argument("--nolds", action="store_true")
 a = ap.parse_args()
 L, R, beta = a.L, a.replicas, a.beta
 n_est = beta * 5.2 * L * L
 cap = 1 << int(np.ceil(np.log2(2.0 * n_est + 4 * L * L)))
-g = im.QmcIsingGraph(lat.two_d_ferro(L), 1.0, 0.0, L * L, 1234, nreplicas=R, capacity=cap, waves_per_replica=a.waves, slots_per_lane=a.k, cfg_flags=1 if a.nolds else 0)
+g = im.QmcIsingGraph(lat.two_d_ferro(L), 1.0, 0.0, L * L, 1234, nreplicas=R, capacity=cap, waves_per_replica=a.waves, slots_per_lane=a.k, cfg_flags=1 if a.nolds else 0, waves_offdiag=a.woff)
 g.run(a.equilibrate, beta)
 print("launch", g.launch_info(), "mean n", g.get_n().mean(), "mean M", g.get_cutoff().mean())
 def t(fn, name):
