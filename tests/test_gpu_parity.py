@@ -235,6 +235,32 @@ def test_rvb_update_matches_oracle(oracle, name, edges, gamma, h, beta, cutoff, 
     assert g.verify().all()
 
 
+@pytest.mark.parametrize("cfgf", [0, 128])
+def test_rvb_dense_windows(oracle, cfgf):
+    """A small lattice at low temperature: most ops touch a sub-variable, so a window's first chunk overflows the gathered-op
+    list (left to the smaller gather steps, which are cut at a wave boundary) and replay batches are full."""
+    edges = lat.two_d_ferro(8)
+    R, beta = 3, 12.0
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 6000, 1 << 14, 9753, R, cfg_flags=cfgf)
+    for it in range(6):
+        g.single_diagonal_step(beta)
+        for rep in reps:
+            rep.diagonal_update(beta)
+            want = rep.n + rep.n // 2
+            if want > rep.cutoff:
+                assert rep.set_cutoff(want) == 0
+        succ, upd = g.single_rvb_sweep()
+        for r, rep in enumerate(reps):
+            assert succ[r] == rep.rvb_update(upd), f"dense: RVB successes differ it={it} r={r}"
+        assert_same(g, reps, f"dense rvb it={it}")
+        g.single_cluster_step(flip_free=True)
+        for rep in reps:
+            rep.cluster_update(0.5)
+            rep.flip_free_spins()
+    assert g.get_n().min() > 2500
+    assert g.verify().all()
+
+
 def test_rvb_fused_timesteps(oracle):
     edges = lat.two_d_periodic(4)
     R = 6
