@@ -317,6 +317,11 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     LaunchCfg lc{};
     lc.W = b->W; lc.K = b->K; lc.mode = b->mode; lc.phase = (domask >> 16) & 1u; lc.stream = b->stream;
     size_lds(b);
+    if (!b->dev.segs2 && (domask & SSE_DO_CLUSTER) && !plan_lds(b, b->W_off ? b->W_off : b->W).all_ids_fit) {
+        // the cluster ids of (some) replicas need the 32-bit union-find in HBM: room for the second id of every slot
+        const int rc2 = dalloc(b, &b->dev.segs2, (size_t)b->dev.R * b->dev.stride, false);
+        if (rc2) return rc2;
+    }
     lc.lds_bytes = ((domask & SSE_DO_RVB) && b->lds_bytes_rvb > b->lds_bytes) ? b->lds_bytes_rvb : b->lds_bytes;
     b->dev.lds_words = (uint32_t)(lc.lds_bytes / 4);
     auto launch_dev = [&](const LaunchCfg &c, const DevBatch &dev, const SweepArgs &a) -> hipError_t {

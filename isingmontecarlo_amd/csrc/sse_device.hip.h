@@ -52,6 +52,7 @@ struct DevBatch {
     double wJ, gamma, wh; // uniform 2|J| (if uniformJ), Gamma, 2|h|
     uint32_t uniformJ, hpos, has_long;
     uint32_t *segs;       // [R][cap] segment ids of every slot's two legs (lo | hi << 16), written by the cluster build
+    uint32_t *segs2;      // [R][stride] second id of each slot when the ids need 32 bits (HBM union-find); nullptr until such a launch is planned
                           // and read by the apply pass of the LDS union-find path (spends spare HBM bandwidth to
                           // avoid recomputing the ordered scan)
     uint32_t *chunks;     // [R][2*SSE_MAX_CHUNKS]: per chunk of CH slots: occupied count, transverse-op count
@@ -815,7 +816,8 @@ __device__ __forceinline__ void uf_union(const UFA<G> &uf, uint32_t a, uint32_t 
 
 // Union on trees that only the calling wave touches (cluster scan): plain stores; lanes that hook the same root in
 // one instruction are detected by reading the parent back.
-__device__ __forceinline__ void uf_union_wave(const UFA<false> &uf, uint32_t a, uint32_t b) {
+template <bool G>
+__device__ __forceinline__ void uf_union_wave(const UFA<G> &uf, uint32_t a, uint32_t b) {
     for (;;) {
         a = uf_find(uf, a);
         b = uf_find(uf, b);
@@ -966,6 +968,10 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                     const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
                     if constexpr (COMPACT) { if (nonempty) row_st(segs_row, pos[j], seg_a | (hi << 16)); } // (lanes past the range end hold no slot)
                     else row_st(segs_row, pos[j], seg_a | (hi << 16));
+                } else if (B.segs2) { // 32-bit ids: two words per slot, so that the apply pass need not repeat the ordered scan
+                    const uint32_t hi = iscut ? id_own : (two ? seg_c : seg_a);
+                    row_st(segs_row, pos[j], seg_a);
+                    row_st(B.segs2 + (size_t)r * B.stride, pos[j], hi);
                 }
             } else {
                 const uint32_t fa = uf.get(seg_a), fc = uf.get(seg_c), fo = uf.get(iscut ? id_own : seg_a);
@@ -976,17 +982,15 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             }
         }
         if constexpr (!APPLY) {
-            if constexpr (G) {
-#pragma unroll
-                for (int j = 0; j < K; ++j) if (utwo[j]) uf_union(uf, ua[j], uc[j]);
-            } else {
+            {
                 // During the scan every wave only touches ids of its own range (its cuts and its placeholders), so
                 // its trees are private until the ranges are joined: no atomics are needed, lanes of the wave that
                 // hook the same root in one store instruction are sorted out by reading the parent back.  The K
-                // unions of the tile go together, three overlapped LDS rounds for all of them: parents, grand-
-                // parents (root test + halving), read-back of the links.  All reads of a batch precede all its
+                // unions of the tile go together, three overlapped rounds of table accesses for all of them: parents,
+                // grandparents (root test + halving), read-back of the links.  All reads of a batch precede all its
                 // stores, so every lane decides on the same snapshot; a link that another lane overwrote (same
-                // root hooked twice) or a chain deeper than two falls back to the serial routine.
+                // root hooked twice) or a chain deeper than two falls back to the serial routine.  The same code serves
+                // the parents in LDS and the 32-bit parents in HBM (one wave's accesses are ordered, as for the tables).
                 uint32_t pa[K], pc[K], ga[K], gc[K], hi[K], lo[K];
                 bool link[K], slow[K];
 #pragma unroll
@@ -1024,26 +1028,27 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
 // Apply pass of the LDS union-find path (cluster.rs:139-167): every slot's segment ids were stored by the build
 // scan, flip bits sit in the (flattened) parent table, so the slots can be rewritten in any order: plain strided
 // streaming, no ordered scan.  Input bits flip with the incoming segment, output bits with the outgoing one.
-template <int W, int K, bool CL>
-__device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<false> &uf) {
+template <int W, int K, bool CL, bool G = false>
+__device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<G> &uf) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t *segs = B.segs + (size_t)r * B.stride;
+    const uint32_t *segs2 = G ? B.segs2 + (size_t)r * B.stride : segs; // 32-bit ids: the second id of a slot has its own row
     // software-pipelined stream over whole tiles (branch-free loads and stores, see diagonal_pass): slots >= M are
     // empty and are written back unchanged
     constexpr uint32_t TS = (uint32_t)(K * NT);
-    uint32_t wn[K], sn[K];
+    uint32_t wn[K], sn[K], tn[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, (uint32_t)(j * NT + tid)); }
+    for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, (uint32_t)(j * NT + tid)); tn[j] = G ? row_ld(segs2, (uint32_t)(j * NT + tid)) : 0u; }
     for (uint32_t p0 = 0; p0 < M; p0 += TS) {
-        uint32_t wd[K], sg[K];
+        uint32_t wd[K], sg[K], sh[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) { wd[j] = wn[j]; sg[j] = sn[j]; }
+        for (int j = 0; j < K; ++j) { wd[j] = wn[j]; sg[j] = sn[j]; sh[j] = tn[j]; }
         {
             const uint32_t pn0 = p0 + TS < M ? p0 + TS : p0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, pn0 + (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, pn0 + (uint32_t)(j * NT + tid)); }
+            for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, pn0 + (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, pn0 + (uint32_t)(j * NT + tid)); if constexpr (G) tn[j] = row_ld(segs2, pn0 + (uint32_t)(j * NT + tid)); }
         }
         uint32_t second[K]; // general bond table: the second variable of the tile's K bonds, requested together
         if constexpr (!CL) {
@@ -1055,7 +1060,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
             const uint32_t w = wd[j];
             const bool nonempty = w != 0u;
             // segment ids of empty slots are stale: read a safe index
-            const uint32_t fa = uf.get(nonempty ? (sg[j] & 0xFFFFu) : 0u), fb = uf.get(nonempty ? (sg[j] >> 16) : 0u);
+            const uint32_t fa = uf.get(nonempty ? (G ? sg[j] : (sg[j] & 0xFFFFu)) : 0u), fb = uf.get(nonempty ? (G ? sh[j] : (sg[j] >> 16)) : 0u);
             bool two;
             if constexpr (CL) two = nonempty & (sse_op_bond(w) < B.E);
             else two = nonempty & (second[j] != SSE_NO_VAR);
@@ -1248,8 +1253,10 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     __syncthreads();
     SSE_STAMP(4);
     // ---- apply (cluster.rs:139-167) ----
-    if constexpr (UF_GLOBAL) cluster_scan<W, K, CL, true, UF_GLOBAL, TG>(B, L, r, M, uf, C);
-    else cluster_apply_cached<W, K, CL>(B, L, r, M, uf);
+    if constexpr (UF_GLOBAL) {
+        if (B.segs2) cluster_apply_cached<W, K, CL, true>(B, L, r, M, uf); // both ids of every slot were stored by the build scan
+        else cluster_scan<W, K, CL, true, UF_GLOBAL, TG>(B, L, r, M, uf, C);  // (a replica that outgrew the LDS union-find before the host planned for it)
+    } else cluster_apply_cached<W, K, CL>(B, L, r, M, uf);
     SSE_STAMP(5);
     // p=0 state follows the placeholder segment of each touched variable
     for (uint32_t i = tid; i < nwords; i += NT) {
