@@ -22,6 +22,7 @@ struct isingmc_batch {
     uint64_t steps_per_launch = 0;
     uint32_t acc_rows = 0;
     uint32_t rvb_updates = 0;
+    bool w8_ok = false;                 // an 8-wave off-diagonal geometry without LDS union-find fits (and the row stride allows it)
     uint32_t *d_acc_row = nullptr;
     size_t lds_bytes = 0, lds_bytes_rvb = 0, lds_fixed_words_ = 0, lds_total_words = 0;
     uint32_t max_ntrans = 0, uf_ids_limit = 0;
@@ -353,11 +354,23 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     // equilibrates; replicas that outgrow the table only fall back to the slower HBM union-find, never fail).
     auto plan_offdiag = [&]() {
         uint32_t Wo = b->W_off ? b->W_off : b->W;
+        bool hbm_uf = false;
         if (!b->W_off && b->W < 16) {
             const LdsPlan p16 = plan_lds(b, 16);
             if (p16.all_ids_fit) Wo = 16;
+            else if (b->w8_ok && !b->uf_ids_limit && !plan_lds(b, b->W).all_ids_fit) {
+                // the largest replicas need the 32-bit union-find in HBM whatever the geometry: spend the LDS on the scan
+                // tables of 8 waves instead of on a 16-bit parent table that they cannot use (the HBM path is bound by
+                // memory latency: twice the waves, twice the accesses in flight)
+                Wo = 8; hbm_uf = true;
+            }
         }
-        const LdsPlan po = plan_lds(b, Wo);
+        LdsPlan po = plan_lds(b, Wo);
+        if (hbm_uf) {
+            const DevBatch &D = b->dev;
+            po.ufcap = 0;
+            po.lds_bytes = (4 * (lds_fixed_words(8, D.N, D.nwords, b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u) + 64) + 7) & ~(size_t)7;
+        }
         lc.W = Wo; lc.lds_bytes = po.lds_bytes;
         dev_off.lds_ufcap = po.ufcap; dev_off.lds_words = (uint32_t)(po.lds_bytes / 4);
         b->last_W_off = Wo;
@@ -670,7 +683,10 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (TG) W_off = W;                               // tables in HBM: one geometry for every launch
     if (W_off && lds_fixed_words(W_off, D.N, D.nwords, ledges, TG) + 64 > total_words) W_off = W;
     const bool w16_possible = !TG && lds_fixed_words(16, D.N, D.nwords, ledges) + 64 <= total_words;
-    const uint32_t Wmax = W_off ? (W_off > W ? W_off : W) : ((W < 16 && w16_possible) ? 16u : W);
+    // (8 waves without an LDS union-find: the geometry of launches whose cluster ids need the 32-bit union-find in HBM anyway)
+    const bool w8_possible = !TG && W < 8 && (K == 4 || K == 1) && lds_fixed_words(8, D.N, D.nwords, ledges) + 64 <= total_words;
+    b->w8_ok = w8_possible && !W_off;
+    const uint32_t Wmax = W_off ? (W_off > W ? W_off : W) : ((W < 16 && w16_possible) ? 16u : (w8_possible ? 8u : W));
     const size_t ids_max = (size_t)Wmax * D.N + D.cap;
     // chunk grid for the per-chunk counters: <= SSE_MAX_CHUNKS chunks of CH slots, CH a multiple of 256
     D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
