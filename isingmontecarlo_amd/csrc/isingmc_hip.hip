@@ -799,7 +799,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         if (hipMemset(D.lite_epoch, 0xFF, sizeof(uint64_t) * D.R) != hipSuccess) { b->err = "hipMemset failed"; return fail(ISINGMC_ENODEVICE); }
     }
     if (TG) {
-        D.tbl_stride = (uint32_t)((((size_t)Wmax * D.N * 3 + D.N) + 15) & ~(size_t)15);
+        D.tbl_stride = (uint32_t)((((size_t)Wmax * D.N * 4 + D.N) + 15) & ~(size_t)15); // 4-byte scan records per (wave, variable)
         if ((rc = dalloc(b, &D.tbl, (size_t)D.R * D.tbl_stride))) return fail(rc);
     }
     if ((rc = dalloc(b, &b->d_beta, D.R))) return fail(rc);

@@ -267,6 +267,13 @@ struct Tab {
     __device__ __forceinline__ void st16(uint32_t reg, uint32_t i, uint32_t v) const { if constexpr (TG) reinterpret_cast<uint16_t *>(g + reg)[i] = (uint16_t)v; else LDSH(reg, i) = (uint16_t)v; }
     __device__ __forceinline__ uint32_t ld32(uint32_t reg, uint32_t i) const { if constexpr (TG) return reinterpret_cast<const uint32_t *>(g + reg)[i]; else return LDSW(reg, i); }
     __device__ __forceinline__ void st32(uint32_t reg, uint32_t i, uint32_t v) const { if constexpr (TG) reinterpret_cast<uint32_t *>(g + reg)[i] = v; else LDSW(reg, i) = v; }
+    // MODE 2 keeps the scan tables of a (wave, variable) pair in ONE 4-byte record {u16 rank, u8 marker, u8 touched}: a leg's
+    // lookups and a cut's stores then hit one 64-B sector of HBM instead of three (that path is bound by random-sector traffic)
+    __device__ __forceinline__ uint32_t rec_ld(uint32_t i) const { return reinterpret_cast<const uint32_t *>(g)[i]; }
+    __device__ __forceinline__ void rec_st(uint32_t i, uint32_t v) const { reinterpret_cast<uint32_t *>(g)[i] = v; }
+    __device__ __forceinline__ void rec_rank_st(uint32_t i, uint32_t v) const { reinterpret_cast<uint16_t *>(g)[2u * i] = (uint16_t)v; }
+    __device__ __forceinline__ void rec_mark_st(uint32_t i, uint32_t v) const { g[4u * i + 2u] = (uint8_t)v; }
+    __device__ __forceinline__ void rec_touch_st(uint32_t i) const { g[4u * i + 3u] = (uint8_t)1u; }
     __device__ __forceinline__ void xor32(uint32_t reg, uint32_t i, uint32_t bits) const {
         if constexpr (TG) __hip_atomic_fetch_xor(reinterpret_cast<uint32_t *>(g + reg) + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicXor(&LDSW(reg, i), bits);
@@ -277,7 +284,7 @@ __device__ __forceinline__ Tab<TG> make_tab(const DevBatch &B, const Lds<W> &L, 
     Tab<TG> T;
     if constexpr (TG) {
         T.g = B.tbl + (size_t)r * B.tbl_stride;
-        T.cur = 0u; T.cl = (uint32_t)W * B.N * 2u; T.touch8 = (uint32_t)W * B.N * 3u; // byte offsets (N is a multiple of 4 in this mode)
+        T.cur = 0u; T.cl = (uint32_t)W * B.N * 2u; T.touch8 = (uint32_t)W * B.N * 4u; // byte offsets (N is a multiple of 4 in this mode); the cluster scan uses the records (rec_*) at offset 0
     } else {
         T.g = nullptr;
         T.cur = L.o_cur; T.cl = L.o_cl; T.touch8 = L.o_touch8;
@@ -854,8 +861,11 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     uint32_t *segs_row = B.segs + (size_t)r * B.stride;
     const uint32_t h_mycur = (uint32_t)wave * N; // element offset of this wave's tables inside o_cur / o_cl
-    for (uint32_t i = tid; i < ((uint32_t)W * N + 1) / 2; i += NT) T.st32(T.cur, i, 0u);
-    for (uint32_t i = tid; i < ((uint32_t)W * N + 3) / 4; i += NT) T.st32(T.cl, i, 0u);
+    if constexpr (TG) { for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) T.rec_st(i, 0u); }
+    else {
+        for (uint32_t i = tid; i < ((uint32_t)W * N + 1) / 2; i += NT) T.st32(T.cur, i, 0u);
+        for (uint32_t i = tid; i < ((uint32_t)W * N + 3) / 4; i += NT) T.st32(T.cl, i, 0u);
+    }
     __syncthreads();
     // this wave's chunk range and the dense id of its first cut
     const uint32_t used = (M + B.CH - 1) / B.CH;
@@ -923,11 +933,17 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             // earlier cuts.  Two cuts of one sub-round on the same variable are rare: a serial loop over the cut
             // lanes (ballot + v_readlane) resolves those.
             if (cutmask) {
-                if (iscut) T.st8(T.cl, h_mycur + va, kown + 1u);
+                if (iscut) { if constexpr (TG) T.rec_mark_st(h_mycur + va, kown + 1u); else T.st8(T.cl, h_mycur + va, kown + 1u); }
                 SSE_WAVE_FENCE();
             }
-            const uint32_t xa = T.ld16(T.cur, h_mycur + va), xc = T.ld16(T.cur, h_mycur + vc);
-            const uint32_t ma = T.ld8(T.cl, h_mycur + va), mc = T.ld8(T.cl, h_mycur + vc);
+            uint32_t xa, xc, ma, mc;
+            if constexpr (TG) {
+                const uint32_t ra = T.rec_ld(h_mycur + va), rc = T.rec_ld(h_mycur + vc);
+                xa = ra & 0xFFFFu; xc = rc & 0xFFFFu; ma = (ra >> 16) & 0xFFu; mc = (rc >> 16) & 0xFFu;
+            } else {
+                xa = T.ld16(T.cur, h_mycur + va); xc = T.ld16(T.cur, h_mycur + vc);
+                ma = T.ld8(T.cl, h_mycur + va); mc = T.ld8(T.cl, h_mycur + vc);
+            }
             uint32_t seg_a = xa ? idbase + xa : my_placeholder_base + va;
             uint32_t seg_c = xc ? idbase + xc : my_placeholder_base + vc;
             if (cutmask) {
@@ -937,7 +953,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                     seg_a = ((ma - 1u) < kown) ? first + (ma - 1u) : seg_a; // ma == 0: no cut on the variable
                     seg_c = ((mc - 1u) < kown) ? first + (mc - 1u) : seg_c;
                     SSE_WAVE_FENCE();
-                    if (iscut) { T.st16(T.cur, h_mycur + va, myrank1); T.st8(T.cl, h_mycur + va, 0u); }
+                    if (iscut) { if constexpr (TG) T.rec_st(h_mycur + va, myrank1 | (1u << 24)); /* rank, marker 0, touched */ else { T.st16(T.cur, h_mycur + va, myrank1); T.st8(T.cl, h_mycur + va, 0u); } }
                 } else {
                     bool lastcut = iscut; // no later cut lane of this sub-round is on the same variable
                     uint64_t m = cutmask;
@@ -953,14 +969,14 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
                         idL++;
                     }
                     SSE_WAVE_FENCE();
-                    if (iscut) T.st8(T.cl, h_mycur + va, 0u);
-                    if (iscut & lastcut) T.st16(T.cur, h_mycur + va, myrank1); // the last cut wins
+                    if (iscut) { if constexpr (TG) T.rec_mark_st(h_mycur + va, 0u); else T.st8(T.cl, h_mycur + va, 0u); }
+                    if (iscut & lastcut) { if constexpr (TG) T.rec_rank_st(h_mycur + va, myrank1); else T.st16(T.cur, h_mycur + va, myrank1); } // the last cut wins
                 }
             }
             nlocal += popc64(cutmask);
             if (!APPLY) {
                 if (iscut) uf.set(id_own, id_own);
-                if (nonempty) { T.st8(T.touch8, va, 1u); T.st8(T.touch8, vc, 1u); }
+                if (nonempty) { if constexpr (TG) { T.rec_touch_st(h_mycur + va); T.rec_touch_st(h_mycur + vc); } else { T.st8(T.touch8, va, 1u); T.st8(T.touch8, vc, 1u); } }
                 ua[j] = seg_a; uc[j] = seg_c;
                 utwo[j] = two & !SSE_DBG(B, 1u); // diagnostic builds: bit 0 = time the scan without unions
                 if (B.has_long) if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
@@ -1147,6 +1163,13 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     // touched bytes -> bits (read by the coins, the p=0 state update and the free-spin pass, all behind later barriers)
     for (uint32_t i = tid; i < nwords; i += NT) {
         uint32_t bits = 0;
+        if constexpr (TG) { // the touched byte of every wave's record of the variable
+            for (uint32_t k = 0; k < 32 && i * 32 + k < N; ++k) {
+                uint32_t t = 0;
+                for (uint32_t w2 = 0; w2 < (uint32_t)W; ++w2) t |= T.rec_ld(w2 * N + i * 32 + k) >> 24;
+                bits |= (t & 1u) << k;
+            }
+        } else
         for (uint32_t k = 0; k < 8 && (i * 8 + k) < (N + 3) / 4; ++k) {
             const uint32_t w = T.ld32(T.touch8, i * 8 + k);
             bits |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * k);
@@ -1158,7 +1181,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     // range wraps around into P(0,v) (cluster.rs:223-242: worldlines are cyclic in imaginary time)
     for (uint32_t i = tid; i < (uint32_t)W * N; i += NT) {
         const uint32_t w2 = i / N, v = i - w2 * N;
-        const uint32_t x = T.ld16(T.cur, i);
+        const uint32_t x = TG ? (T.rec_ld(i) & 0xFFFFu) : T.ld16(T.cur, i);
         const uint32_t last = x ? LDSW(L.o_chg, w2) + x : 0u;
         const uint32_t seg_end = last ? last : (w2 == 0 ? v : N + C + (w2 - 1) * N + v);
         const uint32_t nxt = (w2 + 1 == (uint32_t)W) ? v : N + C + w2 * N + v;
