@@ -940,6 +940,10 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             if constexpr (TG) {
                 const uint32_t ra = T.rec_ld(h_mycur + va), rc = T.rec_ld(h_mycur + vc);
                 xa = ra & 0xFFFFu; xc = rc & 0xFFFFu; ma = (ra >> 16) & 0xFFu; mc = (rc >> 16) & 0xFFu;
+                if constexpr (!APPLY) { // touched flags: stored once per (wave, variable), not once per leg (every store dirties a sector)
+                    if (nonempty & !(ra >> 24)) T.rec_touch_st(h_mycur + va);
+                    if (nonempty & !(rc >> 24)) T.rec_touch_st(h_mycur + vc);
+                }
             } else {
                 xa = T.ld16(T.cur, h_mycur + va); xc = T.ld16(T.cur, h_mycur + vc);
                 ma = T.ld8(T.cl, h_mycur + va); mc = T.ld8(T.cl, h_mycur + vc);
@@ -976,7 +980,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             nlocal += popc64(cutmask);
             if (!APPLY) {
                 if (iscut) uf.set(id_own, id_own);
-                if (nonempty) { if constexpr (TG) { T.rec_touch_st(h_mycur + va); T.rec_touch_st(h_mycur + vc); } else { T.st8(T.touch8, va, 1u); T.st8(T.touch8, vc, 1u); } }
+                if constexpr (!TG) { if (nonempty) { T.st8(T.touch8, va, 1u); T.st8(T.touch8, vc, 1u); } } // (MODE 2: with the record lookups)
                 ua[j] = seg_a; uc[j] = seg_c;
                 utwo[j] = two & !SSE_DBG(B, 1u); // diagnostic builds: bit 0 = time the scan without unions
                 if (B.has_long) if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
