@@ -980,7 +980,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
             nlocal += popc64(cutmask);
             if (!APPLY) {
                 if (iscut) uf.set(id_own, id_own);
-                if constexpr (!TG) { if (nonempty) { T.st8(T.touch8, va, 1u); T.st8(T.touch8, vc, 1u); } } // (MODE 2: with the record lookups)
+                if constexpr (!TG) { if (nonempty & !SSE_DBG(B, 8u)) { T.st8(T.touch8, va, 1u); T.st8(T.touch8, vc, 1u); } } // (MODE 2: with the record lookups; diagnostic builds: bit 3 = time the scan without them)
                 ua[j] = seg_a; uc[j] = seg_c;
                 utwo[j] = two & !SSE_DBG(B, 1u); // diagnostic builds: bit 0 = time the scan without unions
                 if (B.has_long) if (nonempty & (kind == SSE_BOND_LONGITUDINAL)) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31));
