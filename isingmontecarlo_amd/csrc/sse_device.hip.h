@@ -72,7 +72,7 @@ struct DevBatch {
     uint32_t *cops, *cpos; // [R][stride] op words / their slots; null = not allocated
     uint64_t *cops_epoch;  // [R] the update counter at which the list describes the op-string
     uint8_t *tbl;         // [R][tbl_stride] per-variable tables in HBM/L2 for models whose tables exceed LDS (MODE 2, see Tab)
-    uint32_t tbl_stride;  // bytes per replica: Wmax*N*2 (cut ranks / spin bytes) + Wmax*N (cut markers) + N (touched), rounded up to 16
+    uint32_t tbl_stride;  // bytes per replica: Wmax*N*4 (scan records {rank, marker, touched} / spin bytes of the diagonal pass) + N, rounded up to 16
     uint32_t seed_lo, seed_hi, replica_offset;
     const uint32_t *rid;     // [R] or null: identity of the configuration held by each local replica = the `replica` word of its Philox
                              // counters (null: replica_offset + r).  Parallel tempering moves configurations between ranks at
