@@ -64,15 +64,14 @@ __device__ __forceinline__ double &ldsd(uint32_t off, uint32_t i) { return reint
 // words of RVB scratch in front of the constant-op table (mirrors rvb_carve; used by the host to size LDS)
 __host__ __device__ inline uint32_t rvb_fixed_words(uint32_t N, uint32_t E) {
     const uint32_t adj = SSE_RVB_ADJ_LDS && (N < 65535u && E < 65535u) ? (N + 2) / 2 + E : 0u;
-    return 1u + 4 * SSE_RVB_SETCAP + 4 * SSE_RVB_BONDCAP + (N + 1) + N + (N + 1) / 2 + adj + 3 * SSE_RVB_MAXSUB +
-           6 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + 3 * SSE_RVB_SETCAP + SSE_RVB_BONDCAP + 3 * SSE_RVB_GCAP + (E + 1) / 2 + 16 + 8;
+    static_assert(3 * SSE_RVB_GCAP >= 7 * SSE_RVB_SETCAP, "the candidate sets of the large growth area live in the gathered-op lists");
+    return 2u + 4 * SSE_RVB_BONDCAP + (N + 1) + N + (N + 1) / 2 + adj + 3 * SSE_RVB_MAXSUB +
+           6 * SSE_RVB_MAXCL + 2 * SSE_RVB_MAXWIN + SSE_RVB_BONDCAP + 3 * SSE_RVB_GCAP + (E + 1) / 2 + 16 + 8;
 }
 
 template <int W>
 __device__ __forceinline__ void rvb_carve(RvbLds &R, const Lds<W> &L, const DevBatch &B) {
     uint32_t base = (L.o_cur + 1u) & ~1u; // even: doubles are 8-byte aligned
-    R.o_bfw = base; base += 2 * SSE_RVB_SETCAP;
-    R.o_bnw = base; base += 2 * SSE_RVB_SETCAP;
     R.o_bwb = base; base += 2 * SSE_RVB_BONDCAP;
     R.o_bwa = base; base += 2 * SSE_RVB_BONDCAP;
     R.o_vstart = base; base += B.N + 1;
@@ -90,10 +89,11 @@ __device__ __forceinline__ void rvb_carve(RvbLds &R, const Lds<W> &L, const DevB
     R.o_togs = base; base += 2 * SSE_RVB_MAXCL;
     R.o_wfrom = base; base += SSE_RVB_MAXWIN;
     R.o_wuntil = base; base += SSE_RVB_MAXWIN;
-    R.o_bfk = base; base += SSE_RVB_SETCAP;
-    R.o_bfv = base; base += SSE_RVB_SETCAP;
-    R.o_bnk = base; base += SSE_RVB_SETCAP;
     R.o_bk = base; base += SSE_RVB_BONDCAP;
+    base = (base + 1u) & ~1u;
+    // the candidate sets of the large growth area (weights first: doubles) share the gathered-op lists: an attempt is grown
+    // before its first window is fetched, and the lists of the attempt before it are done with by then
+    R.o_bfw = base; R.o_bnw = base + 2 * SSE_RVB_SETCAP; R.o_bfk = base + 4 * SSE_RVB_SETCAP; R.o_bfv = base + 5 * SSE_RVB_SETCAP; R.o_bnk = base + 6 * SSE_RVB_SETCAP;
     R.o_glp = base; base += SSE_RVB_GCAP;
     R.o_glw = base; base += SSE_RVB_GCAP;
     R.o_gli = base; base += SSE_RVB_GCAP;
