@@ -26,7 +26,7 @@ namespace sse {
 #define SSE_RVB_MAXCL 72u      // cluster members (trailing_ones(u64)+1 <= 65)
 #define SSE_RVB_SETCAP 192u    // candidates in each weighted boundary set
 #define SSE_RVB_BONDCAP 288u   // boundary bonds tracked at once
-#define SSE_RVB_GCAP 768u      // gathered ops per batch (any size >= one wave's share of a gather step works)
+#define SSE_RVB_GCAP 512u      // gathered ops per batch (any size >= one wave's share of a gather step works)
 #define SSE_RVB_MAXWIN 80u     // time windows of one attempt
 
 struct RvbLds { // word offsets into lds_raw
