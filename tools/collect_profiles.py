@@ -6,9 +6,9 @@ R = os.environ.get("ROUND", "r02")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW, OUT = os.path.join(ROOT, "gpurun_out", "profiles_raw"), os.path.join(ROOT, "profiles")
 # (gpurun merges every call's output: pick this round's stats file, the one that saw the trimmed diagonal kernel)
-stats = [f for f in sorted(glob.glob(os.path.join(RAW, "stats", "*", "*_kernel_stats.csv"))) if "sweep_fast_kernel" in open(f).read()]
+stats = [f for f in sorted(glob.glob(os.path.join(RAW, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime) if "sweep_fast_kernel" in open(f).read()]  # newest last
 shutil.copy(stats[-1], os.path.join(OUT, R + "_kernel_stats.csv"))
-stats_rvb = sorted(glob.glob(os.path.join(RAW, "stats_rvb", "*", "*_kernel_stats.csv")))
+stats_rvb = sorted(glob.glob(os.path.join(RAW, "stats_rvb", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if stats_rvb:
     shutil.copy(stats_rvb[-1], os.path.join(OUT, R + "_kernel_stats_config2_rvb.csv"))
 for f in glob.glob(os.path.join(RAW, R + "_*.json")) + glob.glob(os.path.join(RAW, R + "_*.txt")):
@@ -24,7 +24,7 @@ def kind(k):
         return "diagonal"
     return None
 def keep(src_dir, out):
-    src = [f for f in sorted(glob.glob(os.path.join(RAW, src_dir, "*", "*_counter_collection.csv"))) if "sweep_fast_kernel" in open(f).read()][-1]
+    src = [f for f in sorted(glob.glob(os.path.join(RAW, src_dir, "*", "*_counter_collection.csv")), key=os.path.getmtime) if "sweep_fast_kernel" in open(f).read()][-1]
     rows = list(csv.reader(open(src))); hdr = rows[0]; ki = hdr.index("Kernel_Name")
     sel = [r for r in rows[1:] if kind(r[ki])]
     csv.writer(open(os.path.join(OUT, out), "w")).writerows([hdr] + sel)
