@@ -927,7 +927,7 @@ struct GrowArea {
     uint32_t cap_set, cap_cl, cap_sub, cap_win;
 };
 enum { GO_NSUB = 0, GO_NWIN = 1, GO_NTOG = 2, GO_K = 3, GO_ERR = 4 };
-#define SSE_RVB_SLOT_SET 48u // (<= 64: the keys of a small area live in registers)
+#define SSE_RVB_SLOT_SET 64u // (<= 64: the keys of a small area live in registers)
 #define SSE_RVB_SLOT_CL 16u
 #define SSE_RVB_SLOT_SUB (SSE_RVB_SLOT_CL + 2u * SSE_RVB_SLOT_SET)
 #define SSE_RVB_SLOT_WIN (SSE_RVB_SLOT_CL + 2u)
