@@ -931,7 +931,7 @@ enum { GO_NSUB = 0, GO_NWIN = 1, GO_NTOG = 2, GO_K = 3, GO_ERR = 4 };
 #define SSE_RVB_SLOT_CL 16u
 #define SSE_RVB_SLOT_SUB (SSE_RVB_SLOT_CL + 2u * SSE_RVB_SLOT_SET)
 #define SSE_RVB_SLOT_WIN (SSE_RVB_SLOT_CL + 2u)
-#define SSE_RVB_SLOT_WORDS (4u * SSE_RVB_SLOT_SET + 4u * SSE_RVB_SLOT_CL + 3u * SSE_RVB_SLOT_SUB + 2u * SSE_RVB_SLOT_WIN + 8u)
+#define SSE_RVB_SLOT_WORDS (4u * SSE_RVB_SLOT_SET + 4u * SSE_RVB_SLOT_CL + 2u * SSE_RVB_SLOT_SUB + 2u * SSE_RVB_SLOT_WIN + 8u)
 __device__ __forceinline__ GrowArea grow_area_small(uint32_t base) { // base even (doubles)
     GrowArea A;
     A.cap_set = SSE_RVB_SLOT_SET; A.cap_cl = SSE_RVB_SLOT_CL; A.cap_sub = SSE_RVB_SLOT_SUB; A.cap_win = SSE_RVB_SLOT_WIN;
@@ -942,7 +942,8 @@ __device__ __forceinline__ GrowArea grow_area_small(uint32_t base) { // base eve
     A.o_togs = base; base += 2 * A.cap_cl;
     A.o_sub = base; base += A.cap_sub;
     A.o_sfl = base; base += A.cap_sub;
-    A.o_tmp = base; base += A.cap_sub;
+    static_assert(4u * SSE_RVB_SLOT_SET >= SSE_RVB_SLOT_SUB, "the sort scratch of a small area lives in its weight arrays");
+    A.o_tmp = A.o_bfw; // (the candidate weights are dead once the cluster has its members: their room serves the sort)
     A.o_wfrom = base; base += A.cap_win;
     A.o_wuntil = base; base += A.cap_win;
     A.o_out = base;
