@@ -206,6 +206,7 @@ RVB_CASES = [
     ("villain3", lat.two_d_periodic(3), 1.0, 0.0, 1.5, 9),
     ("villain4", lat.two_d_periodic(4), 1.0, 0.0, 2.0, 16),
     ("ferro8x8", lat.two_d_ferro(8), 1.0, 0.0, 3.0, 64),
+    ("ferro8x8_long", lat.two_d_ferro(8), 1.0, 0.3, 3.0, 64),   # longitudinal ops inside clusters zero the weight ratio
     ("ferro16x16_b4", lat.two_d_ferro(16), 1.0, 0.0, 4.0, 256),  # thousands of attempts: clusters that outgrow a small growth area
 ]
 
