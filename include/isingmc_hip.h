@@ -61,6 +61,8 @@ extern "C" {
                                    launches trade 0.1 ms for 0.1 ms, see DESIGN.md, so it is off by default) */
 #define ISINGMC_CFG_RVB_SERIAL_GROWTH 128u /* RVB sweeps grow the clusters of their attempts one at a time instead of a batch of them side by
                                             side on the waves of the workgroup (testing: the results are the same either way) */
+#define ISINGMC_CFG_NO_LEAN_CLUSTER 256u /* run cluster updates through the general kernel even where the dedicated one (csrc/sse_cluster.hip.h:
+                                           LDS edge tables, N <= 4095, default wave counts) applies (testing / A-B timing) */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 

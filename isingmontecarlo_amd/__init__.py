@@ -14,7 +14,7 @@ from . import _build
 
 __all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "NativeTemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
            "interaction_at", "interaction_sym_under_ising",
-           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J", "CFG_GLOBAL_TABLES", "CFG_NO_FAST_DIAG", "CFG_FAST_LABEL", "CFG_COMPACT", "CFG_RVB_SERIAL_GROWTH"]
+           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J", "CFG_GLOBAL_TABLES", "CFG_NO_FAST_DIAG", "CFG_FAST_LABEL", "CFG_COMPACT", "CFG_RVB_SERIAL_GROWTH", "CFG_NO_LEAN_CLUSTER"]
 
 FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
 FLAG_PREP = 0x10000
@@ -25,6 +25,7 @@ CFG_NO_FAST_DIAG = 16  # general diagonal kernel even where the trimmed one appl
 CFG_FAST_LABEL = 32  # experimental: segment labelling rides on the trimmed diagonal kernel (same results, currently slower)
 CFG_RVB_SERIAL_GROWTH = 128  # RVB attempts grow their clusters one at a time (testing; same results)
 CFG_COMPACT = 64  # experimental: cluster update scans the dense op list written by the trimmed diagonal kernel (same results, no net gain yet)
+CFG_NO_LEAN_CLUSTER = 256  # general cluster kernel even where the dedicated one applies (testing / A-B timing)
 CFG_FUSED_LAUNCH = 2  # whole timesteps in one kernel launch (default: diagonal launch + off-diagonal launch)
 ALL = 0xFFFFFFFF
 
@@ -541,7 +542,7 @@ class QmcIsingGraph:
         out = (C.c_uint32 * 8)()
         self._check(self._lib.isingmc_get_launch_info(self._h, out))
         return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3],
-                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), global_tables=bool(out[6] & 2), fast_diagonal=bool(out[6] & 4), fast_label=bool(out[6] & 8), compact_list=bool(out[6] & 16),
+                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), global_tables=bool(out[6] & 2), fast_diagonal=bool(out[6] & 4), fast_label=bool(out[6] & 8), compact_list=bool(out[6] & 16), lean_cluster=bool(out[6] & 32),
                     waves_offdiag=(out[6] >> 8) & 0xFF,
                     lds_bytes_diagonal=out[7])
 

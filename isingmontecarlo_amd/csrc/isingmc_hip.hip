@@ -36,6 +36,8 @@ struct isingmc_batch {
     bool compact = false;               // ... and it writes the dense op list for the cluster update that follows in the same timestep
     bool lite = false;                  // ... or (experimental) labels the segments for the cluster update that follows in the same timestep
     bool fused_launch = false;          // ISINGMC_CFG_FUSED_LAUNCH: whole timesteps in one kernel (no diagonal-only launches)
+    bool lean_cluster = false;          // cluster (+ free spins + sampling) launches use sse_cluster.hip.h when their ids fit its LDS union-find
+    bool last_lean = false;             // ... and the last such launch did
     std::vector<hipEvent_t> evpool;     // per-launch events of the split path (bounded, see run())
     float pass_ms[2] = {0.f, 0.f};      // [0] diagonal-only launches, [1] all other launches of the last run
     uint32_t pass_launches[2] = {0, 0};
@@ -254,6 +256,24 @@ static void size_lds(isingmc_batch *b) {
     b->lds_bytes = p.lds_bytes;
 }
 
+// LDS plan of the dedicated cluster kernel (sse_cluster.hip.h): 16 waves, packed per-wave tables, 16-bit parents for
+// 16 N + (transverse ops seen so far + headroom) ids.  ok = false: the ids do not fit (the general kernel takes the launch).
+struct LeanPlan { bool ok; uint32_t ufcap; size_t lds_bytes; };
+static LeanPlan plan_lean(const isingmc_batch *b) {
+    const DevBatch &D = b->dev;
+    LeanPlan p{false, 0u, 0};
+    if (!b->lean_cluster) return p;
+    const size_t fixed = cluster_fixed_words(D.N, D.nwords, D.Nb);
+    const size_t ids_max = (size_t)16 * D.N + D.cap;
+    size_t want = (size_t)16 * D.N + b->max_ntrans + b->max_ntrans / 16 + 384;
+    if (want > ids_max) want = ids_max;
+    if (want > 65535) return p;
+    const size_t words = fixed + (want + 1) / 2 + (D.has_long ? 2 * ((want + 31) / 32) : 0);
+    if (words > b->lds_total_words) return p;
+    p.ok = true; p.ufcap = (uint32_t)want; p.lds_bytes = (4 * words + 7) & ~(size_t)7;
+    return p;
+}
+
 static int check_errors(isingmc_batch *b) {
     std::vector<uint32_t> err(b->dev.R), ntr(b->dev.R);
     HIP_TRY(b, hipMemcpyAsync(err.data(), b->dev.err, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost, b->stream));
@@ -402,13 +422,37 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         lc.passes = SSE_PASSES_OFFDIAG;
         plan_offdiag();
     }
+    // The cluster (+ free spins + sampling) launch of the headline geometry: the dedicated kernel, then the general one for the
+    // replicas it flagged (ids beyond its LDS union-find, no op, no cut: a handful while a batch equilibrates, none afterwards;
+    // that launch runs in the small diagonal geometry and its workgroups leave at once when their flag is clear).
+    bool lean_now = false;
+    LeanPlan lean{};
+    auto plan_lean_now = [&]() { lean = plan_lean(b); lean_now = lean.ok && (b->K == 4 || b->K == 2) && !b->uf_ids_limit; b->last_lean = lean_now; };
+    plan_lean_now();
+    auto launch_lean = [&](const SweepArgs &a) -> hipError_t {
+        LaunchCfg ll = lc;
+        ll.W = 16; ll.K = b->K; ll.lds_bytes = lean.lds_bytes;
+        DevBatch dv = b->dev;
+        dv.lds_ufcap = lean.ufcap; dv.lds_words = (uint32_t)(lean.lds_bytes / 4);
+        hipError_t e = launch_cluster(ll, dv, a);
+        if (e != hipSuccess) return e;
+        LaunchCfg lf = lc;
+        lf.W = b->W; lf.passes = SSE_PASSES_OFFDIAG;
+        const LdsPlan pf = plan_lds(b, b->W);
+        DevBatch df = b->dev;
+        lf.lds_bytes = pf.lds_bytes; df.lds_ufcap = pf.ufcap; df.lds_words = (uint32_t)(pf.lds_bytes / 4);
+        SweepArgs af = a;
+        af.only_flagged = 1u;
+        return launch_dev(lf, df, af);
+    };
     HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
     if (!split) {
         const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;
         for (uint64_t done = 0; done < nsteps; done += per) {
             A.step0 = done;
             A.nsteps = (nsteps - done < per) ? nsteps - done : per;
-            const hipError_t e = launch_dev(lc, (use_dev_off || lc.passes == SSE_PASSES_OFFDIAG) ? dev_off : b->dev, A);
+            const bool lean_here = lean_now && A.nsteps == 1 && (A.domask & SSE_DO_CLUSTER) && !(A.domask & ~(SSE_DO_CLUSTER | SSE_DO_FREE));
+            const hipError_t e = lean_here ? launch_lean(A) : launch_dev(lc, (use_dev_off || lc.passes == SSE_PASSES_OFFDIAG) ? dev_off : b->dev, A);
             if (e != hipSuccess) return fail_launch(e);
             launches++;
         }
@@ -437,6 +481,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
                 int rcq = check_errors(b); // drains the stream, refreshes max_ntrans; an error ends the call here
                 if (rcq) return rcq;
                 plan_offdiag();
+                plan_lean_now();
             }
             const bool timed = done < MAX_TIMED;
             SweepArgs a1 = A;
@@ -469,7 +514,10 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
                     const LdsPlan po = plan_lds(b, lc.W);
                     DevBatch dv = use_dev_off ? dev_off : b->dev;
                     lo.lds_bytes = po.lds_bytes; dv.lds_ufcap = po.ufcap; dv.lds_words = (uint32_t)(po.lds_bytes / 4);
-                    e = launch_dev(lo, dv, a2);
+                    if (lean_now && (rest2 & SSE_DO_CLUSTER) && !(rest2 & ~(SSE_DO_CLUSTER | SSE_DO_FREE))) e = launch_lean(a2);
+                    else e = launch_dev(lo, dv, a2);
+                } else if (lean_now && (rest2 & SSE_DO_CLUSTER) && !(rest2 & ~(SSE_DO_CLUSTER | SSE_DO_FREE))) {
+                    e = launch_lean(a2);
                 } else
                 e = launch_dev(lc, (use_dev_off || lc.passes == SSE_PASSES_OFFDIAG) ? dev_off : b->dev, a2);
                 if (e != hipSuccess) return fail_launch(e);
@@ -704,6 +752,9 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     b->fast_diag = CL && !TG && W == 4 && (K == 4 || K == 2) && D.N <= SSE_FAST_MAX_VARS && !b->fused_launch &&
                    !(cfg->flags & ISINGMC_CFG_NO_FAST_DIAG) && b->lds_bytes_fast <= 40 * 1024; // 4 workgroups per CU
     // ... and labels the segments for the cluster update of the same timestep (h = 0: no frozen segments to track)
+    // the cluster update of that geometry has its own kernel too (16 waves, packed tables; sse_cluster.hip.h)
+    b->lean_cluster = CL && !TG && !generic && D.N <= 4095u && !b->fused_launch && !cfg->waves_offdiag && !cfg->waves_per_replica &&
+                      !(cfg->flags & ISINGMC_CFG_NO_LEAN_CLUSTER);
     b->lds_bytes_fast_label = fast_lds_bytes(D.N, D.nwords, D.E, D.Nb, true);
     // (opt-in as well: the diagonal launch pays for the two extra stores per op what the shorter scan gains)
     b->compact = b->fast_diag && (cfg->flags & ISINGMC_CFG_COMPACT) && !(cfg->flags & ISINGMC_CFG_FAST_LABEL);
@@ -1172,7 +1223,7 @@ int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u) | (b->lite ? 8u : 0u) | (b->compact ? 16u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
+    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u) | (b->lite ? 8u : 0u) | (b->compact ? 16u : 0u) | (b->last_lean ? 32u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
     return ISINGMC_OK;
 }
 

@@ -118,6 +118,7 @@ struct SweepArgs {
     double prob;
     uint32_t rvb_updates; // RVB attempts per step (0 = (N+1)/2, qmc_ising.rs:711)
     uint32_t *out_u32; // optional per-replica output (n_clusters / loop length / RVB successes) of the LAST step
+    uint32_t only_flagged; // 1 = run only the replicas flagged in DevBatch::aux (left over by sse::cluster_kernel) and clear their flags
 };
 
 // scalar add that the optimiser may not hoist or merge: the ten round keys are wave-uniform and loop-invariant,
@@ -1527,6 +1528,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
     L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u, B.has_long, TG);
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
+    if (A.only_flagged && !B.aux[r]) return; // (uniform per workgroup; the flag is cleared at the end, behind the barriers below)
     if (B.bond_stride) { // per-replica couplings: this replica's tables (B is this workgroup's private copy)
         const uint32_t hr = B.ham_row ? B.ham_row[r] : r;
         B.bonds += (size_t)hr * B.bond_stride;
@@ -1631,6 +1633,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         if (A.out_u32) A.out_u32[r] = last_out;
         uint64_t *acc = B.acc + (size_t)B.acc_row[r] * 8;
         acc[0] += a0; acc[1] += a1; acc[2] += a2; acc[3] += a3; acc[4] += a4; acc[5] += a5; acc[6] += a6;
+        if (A.only_flagged) B.aux[r] = 0u;
     }
 }
 
@@ -1646,6 +1649,8 @@ hipError_t launch_sweep_w6(const LaunchCfg &c, const DevBatch &B, const SweepArg
 hipError_t launch_sweep_w8(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_w16(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_sweep_fast(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A); // sweep_fast.hip: sse_fast.hip.h, W = 4
+hipError_t launch_cluster(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);    // sweep_cluster.hip: sse_cluster.hip.h, W = 16
+size_t cluster_fixed_words(uint32_t N, uint32_t nwords, uint32_t Nb);                    // LDS words of that kernel in front of its parent table
 
 template <int W, int K, int CL, int PHASE, int PASSES>
 hipError_t launch_one(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {

@@ -741,3 +741,43 @@ def test_64x64_cold_end_runs_on_the_hbm_union_find_and_matches(oracle):
     bonds = (reps[0].ops() >> 4).astype(np.int64) - 1
     ntrans = int(((bonds >= len(edges)) & (bonds < len(edges) + g.nvars)).sum())
     assert g.nvars + ntrans > 65535 and reps[0].cutoff > 300000
+
+
+# The dedicated cluster kernel (csrc/sse_cluster.hip.h) against the oracle, in the situations that take its different
+# branches: h = 0 and h != 0 (frozen clusters), slots_per_lane 4 and 2, with a directed loop in front, single primitives, replicas
+# it leaves to the general kernel (no cut / no op at high temperature, ids beyond the union-find planned before the first
+# launch), and the same runs through the general kernel only (CFG_NO_LEAN_CLUSTER) for the A-B switch.
+@pytest.mark.parametrize("k", [0, 2])
+@pytest.mark.parametrize("nolean", [False, True])
+@pytest.mark.parametrize("name,edges,gamma,h,beta,cut0", [
+    ("ferro16", lat.two_d_ferro(16), 1.0, 0.0, 4.0, 256),
+    ("ferro8_long", lat.two_d_ferro(8), 1.0, 0.25, 3.0, 64),
+    ("ring8_hot", lat.one_d_periodic(8), 0.4, 0.0, 0.3, 8),
+    ("villain8_cold", lat.two_d_periodic(8), 1.0, 0.0, 8.0, 64),
+])
+def test_dedicated_cluster_kernel(oracle, name, edges, gamma, h, beta, cut0, nolean, k):
+    import isingmontecarlo_amd as im
+    R = 12
+    g, m, reps = make_pair(oracle, edges, gamma, h, cut0, 1 << 15, 4711, R, k=k, cfg_flags=im.CFG_NO_LEAN_CLUSTER if nolean else 0)
+    g.run(12, beta, sampling_freq=2)
+    oracle.batch_timesteps(reps, 12, [beta] * R, 2, 0)
+    assert g.launch_info()["lean_cluster"] == (not nolean)
+    assert_same(g, reps, f"{name} timesteps")
+    for it in range(6):
+        g.single_diagonal_step(beta)
+        for rep in reps:
+            rep.diagonal_update(beta)
+            want = rep.n + rep.n // 2
+            if want > rep.cutoff:
+                assert rep.set_cutoff(want) == 0
+        nc = g.single_cluster_step(flip_free=False)
+        for r, rep in enumerate(reps):
+            assert nc[r] == rep.cluster_update(0.5), f"{name}: cluster count differs it={it} r={r}"
+        assert_same(g, reps, f"{name} cluster it={it}")
+    g.run(10, beta, flags=1, sampling_freq=3)
+    oracle.batch_timesteps(reps, 10, [beta] * R, 3, 1)
+    assert_same(g, reps, f"{name} + loop")
+    acc = g.accumulators()
+    for r, rep in enumerate(reps):
+        assert np.array_equal(acc[r, :7], rep.accumulators()[:7]), f"accumulators differ r={r}: {acc[r]} vs {rep.accumulators()}"
+    assert g.verify().all()

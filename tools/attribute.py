@@ -33,4 +33,6 @@ for spec in a.flags:
         print(f"flags {f:#04x}: {ms:7.3f} ms   compute {tk[8]:.0f} rounds {tk[9]:.0f} commit {tk[11]:.0f} us; rounds/tile {out[:,13].sum()/max(1,out[:,12].sum()):.2f}")
     else:
         print(f"flags {f:#04x}: {ms:7.3f} ms   init %.0f build %.0f join %.0f flatten %.0f coins %.0f apply %.0f us" % tuple(tk[:6]))
+        c = out.astype(float).mean(axis=0)
+        if c[11] > 0: print("   wave 3 of a replica: %.0f tiles, %.0f rows with a union, %.0f shader cycles in the union blocks (%.0f of them in the serial routine); need lanes %.0f, successful write-backs %.0f, last (old<<32|expected) %x" % (c[11], c[8], c[9], c[10], c[12], c[13], int(out[0, 14])))
     del g

@@ -4,7 +4,7 @@ import re, sys, collections
 path, key, a, b = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and key in l and re.match(r"^\S+:", l))
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
 ins = []
 for l in lines[start:end + 1]:
     t = l.strip()

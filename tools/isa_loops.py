@@ -4,7 +4,7 @@ import re, sys
 path, key = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and key in l and re.match(r"^\S+:", l))
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))  # (kernels with early returns hold several s_endpgm)
 body = lines[start:end + 1]
 labels, ins = {}, []
 for l in body:
