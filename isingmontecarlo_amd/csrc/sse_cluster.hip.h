@@ -37,9 +37,17 @@ namespace sse {
 #define SSE_CLE_CUT (1u << 31)
 #define SSE_CL_TOUCHED (1u << 24)
 
-#define LDS32B(a) (*reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(lds_raw) + (a)))
-#define LDS16B(a) (*reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(lds_raw) + (a)))
-#define LDS8B(a) (reinterpret_cast<uint8_t *>(lds_raw)[(a)])
+// LDS accesses of the hot loops by ABSOLUTE LDS byte address held in a 32-bit register (bases below include the address of
+// lds_raw): written as pointer arithmetic on lds_raw every access costs an extra v_add of the symbol's (link-time) address
+typedef __attribute__((address_space(3))) uint32_t sse_lds_u32;
+typedef __attribute__((address_space(3))) uint16_t sse_lds_u16;
+typedef __attribute__((address_space(3))) uint8_t sse_lds_u8;
+#define LDS32B(a) (*(sse_lds_u32 *)(uintptr_t)(a))
+#define LDS16B(a) (*(sse_lds_u16 *)(uintptr_t)(a))
+#define LDS8B(a) (*(sse_lds_u8 *)(uintptr_t)(a))
+__device__ __forceinline__ void lds_cas32(uint32_t addr, uint32_t expect, uint32_t val) { // ds_cmpst_b32, result unused
+    (void)__hip_atomic_compare_exchange_strong((sse_lds_u32 *)(uintptr_t)addr, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 struct ClLds { // word offsets into lds_raw
     uint32_t o_tab;    // [Nb + 1]   packed bond entries, at word 0 (the index is the op word >> 4)
@@ -143,8 +151,9 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
     for (int off = 32; off > 0; off >>= 1) cutbase += __shfl_xor(cutbase, off);
     cutbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cutbase);
     const uint32_t pbeg = c0 * B.CH, pend = min(c1 * B.CH, M); // whole tiles except at the end of the string, where the row holds zeros
-    const uint32_t ent_b = 4u * (L.o_ent + (uint32_t)wave * (N + 1u)); // byte address of this wave's table
-    const uint32_t par_b = 4u * L.o_parent;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(sse_lds_u32 *)lds_raw; // LDS address of the dynamic region
+    const uint32_t ent_b = lds0 + 4u * (L.o_ent + (uint32_t)wave * (N + 1u)); // LDS address of this wave's table
+    const uint32_t par_b = lds0 + 4u * L.o_parent;
 
     SSE_STAMP(0);
     // ---- build: label every leg, union through the two-site ops (cluster.rs:193-271) ----
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
 #pragma unroll
                 for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, pn0 + (uint32_t)(j * 64 + lane));
 #pragma unroll
-                for (int j = 0; j < K; ++j) e[j] = LDS32B((word[j] >> 2) & ~3u); // entry (word >> 4) of the table at LDS word 0
+                for (int j = 0; j < K; ++j) e[j] = LDS32B(lds0 + 4u * (word[j] >> 4)); // entry (word >> 4) of the table at LDS word 0
             }
             uint32_t ua[K], uc[K], adra[K], adrc[K];
 #pragma unroll
@@ -192,11 +201,7 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                 if (iscut) LDS8B(aa + 2u) = (uint8_t)(kown + 1u);
                 SSE_WAVE_FENCE();
                 const uint32_t ea = LDS32B(aa), ec = LDS32B(ac);
-                // touched flag (byte 3): stored once per (wave, variable); afterwards the whole wave skips the stores
-                if (sse_any(((ea & ec) >> 24) == 0u)) {
-                    if ((ea >> 24) == 0u) LDS8B(aa + 3u) = (uint8_t)1;
-                    if ((ec >> 24) == 0u) LDS8B(ac + 3u) = (uint8_t)1;
-                }
+                LDS8B(aa + 3u) = (uint8_t)1; LDS8B(ac + 3u) = (uint8_t)1; // touched flag (byte 3): plain stores with an immediate offset, nothing waits for them
                 const uint32_t qa = (ea >> 16) & 0xFFu, qc = (ec >> 16) & 0xFFu;
                 uint32_t seg_a = ea & 0xFFFFu, seg_c = ec & 0xFFFFu;
                 const uint64_t dup = cutm & sse_ballot(qa != kown + 1u);
@@ -273,8 +278,8 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                       const uint32_t o2 = atomicCAS(&LDS32B(adrc[j]), uc[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
                       if (wave == 3) { atomicAdd(&B.dbg[(size_t)r * 16 + 13], (unsigned long long)((o1 == (ua[j] | SSE_CL_TOUCHED)) + (o2 == (uc[j] | SSE_CL_TOUCHED)))); if (lane == __builtin_amdgcn_readfirstlane(lane)) B.dbg[(size_t)r * 16 + 14] = ((unsigned long long)o1 << 32) | (ua[j] | SSE_CL_TOUCHED); } }
 #else
-                    atomicCAS(&LDS32B(adra[j]), ua[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
-                    atomicCAS(&LDS32B(adrc[j]), uc[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
+                    lds_cas32(adra[j], ua[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
+                    lds_cas32(adrc[j], uc[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
 #endif
                 }
             }
