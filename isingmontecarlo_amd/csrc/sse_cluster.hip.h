@@ -115,7 +115,8 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
     const uint32_t C = B.ntrans[r], M = B.cutoff[r], err = B.err[r];
     if (err) return;                                  // sticky error: the general kernel would not touch the replica either
     const uint32_t S = N + C + (uint32_t)(W - 1) * N; // ids: initial segments, cuts, range-boundary placeholders
-    if (n == 0 || C == 0u || S > B.lds_ufcap || S > 65535u) { // not this kernel's case: the general one follows up
+    if (n == 0 || C == 0u || S >= B.lds_ufcap || S >= 65535u) { // not this kernel's case: the general one follows up (id S itself is the
+                                                               // null id of empty slots: a table entry of its own, its flip bit stays 0)
         if (tid == 0) B.aux[r] = 1u;
         return;
     }
@@ -136,9 +137,9 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
     // per-wave tables: the segment a variable is in when the wave's range begins = the placeholder id of (wave, variable)
     for (uint32_t i = tid; i < (uint32_t)W * (N + 1u); i += NT) {
         const uint32_t w2 = i / (N + 1u), v = i - w2 * (N + 1u);
-        LDSW(L.o_ent, i) = v == N ? 0u : (w2 == 0u ? v : N + C + (w2 - 1u) * N + v);
+        LDSW(L.o_ent, i) = v == N ? S : (w2 == 0u ? v : N + C + (w2 - 1u) * N + v); // (the dummy variable of empty slots carries the null id S)
     }
-    for (uint32_t i = tid; i < (S + 1u) / 2u; i += NT) LDSW(L.o_parent, i) = (2u * i) | ((2u * i + 1u) << 16); // parent[i] = i
+    for (uint32_t i = tid; i < S / 2u + 1u; i += NT) LDSW(L.o_parent, i) = (2u * i) | ((2u * i + 1u) << 16); // parent[i] = i for i <= S
     if constexpr (HAS_LONG) for (uint32_t i = tid; i < (S + 31u) / 32u; i += NT) uf.bits_clear(i);
     __syncthreads();
 
@@ -244,16 +245,10 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
             // addresses would cost the LDS more than the whole scan).  Parents, grandparents (root test), link + read-back (two lanes
             // hooking one root); the trees a wave touches during the scan are private to it (own cuts, own placeholders): plain
             // stores, no atomics.  Anything deeper goes through the serial routine.
-#ifdef SSE_PHASE_TIMING
-            const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
-#endif
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const bool need = ua[j] != uc[j];
                 if (!sse_any(need) || SSE_DBG(B, 2u)) continue; // wave-uniform
-#ifdef SSE_PHASE_TIMING
-                if (lane == 0 && wave == 3) { B.dbg[(size_t)r * 16 + 8] += 1; B.dbg[(size_t)r * 16 + 12] += popc64(sse_ballot(need)); }
-#endif
                 if (need) {
                     const uint32_t pa = LDS16B(par_b + 2u * ua[j]), pc = LDS16B(par_b + 2u * uc[j]);
                     const uint32_t ga = LDS16B(par_b + 2u * pa), gc = LDS16B(par_b + 2u * pc);
@@ -265,27 +260,12 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                     if (link) LDS16B(par_b + 2u * hi) = (uint16_t)lo;
                     SSE_WAVE_FENCE();
                     const uint32_t chk = LDS16B(par_b + 2u * hi);
-#ifdef SSE_PHASE_TIMING
-                    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-#endif
                     if ((differ & !roots) | (link & (chk != lo))) lo = cl_union_wave(uf, pa, pc);
-#ifdef SSE_PHASE_TIMING
-                    if (wave == 3 && lane == __builtin_amdgcn_readfirstlane(lane)) B.dbg[(size_t)r * 16 + 10] += __builtin_amdgcn_s_memtime() - ts0;
-#endif
                     // both legs' entries now name the surviving root (or the common parent found one hop up)
-#ifdef SSE_PHASE_TIMING
-                    { const uint32_t o1 = atomicCAS(&LDS32B(adra[j]), ua[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
-                      const uint32_t o2 = atomicCAS(&LDS32B(adrc[j]), uc[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
-                      if (wave == 3) { atomicAdd(&B.dbg[(size_t)r * 16 + 13], (unsigned long long)((o1 == (ua[j] | SSE_CL_TOUCHED)) + (o2 == (uc[j] | SSE_CL_TOUCHED)))); if (lane == __builtin_amdgcn_readfirstlane(lane)) B.dbg[(size_t)r * 16 + 14] = ((unsigned long long)o1 << 32) | (ua[j] | SSE_CL_TOUCHED); } }
-#else
                     lds_cas32(adra[j], ua[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
                     lds_cas32(adrc[j], uc[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
-#endif
                 }
             }
-#ifdef SSE_PHASE_TIMING
-            if (lane == 0 && wave == 3) { B.dbg[(size_t)r * 16 + 9] += __builtin_amdgcn_s_memtime() - tu0; B.dbg[(size_t)r * 16 + 11] += 1; }
-#endif
         }
         if (pbeg < pend) {
 #pragma unroll
@@ -367,6 +347,7 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
             uf.set(i, (!isfrozen && u01(o.x) < A.prob) ? 1u : 0u);
         }
     }
+    if (tid == 0) uf.set(S, 0u); // the null id never flips
     {
         uint32_t c = myclusters;
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -403,27 +384,27 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
 #pragma unroll
                 for (int j = 0; j < K; j += 2) inext[j / 2] = row_ld(ids, (pn0 >> 1) + (uint32_t)(j * 32 + lane));
             }
-            uint32_t f1[K], f2[K], b1[K];
-            bool iscut[K];
+            // straight-line: both flip lookups are issued for every lane (lanes that hold no cut read a valid id, at most the first
+            // id of the next range; empty slots carry the null id, whose flip is 0, so their word stays 0 without a test)
+            uint32_t f1[K], f2[K];
+            uint64_t cutm[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                b1[j] = word[j] >> 4;
-                iscut[j] = (b1[j] - E1) < N; // bonds [E, E + N): transverse field
-                const uint64_t cutm = sse_ballot(iscut[j]);
-                const uint32_t own = __builtin_amdgcn_mbcnt_hi((uint32_t)(cutm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cutm, cutnext));
+                cutm[j] = sse_ballot(((word[j] >> 4) - E1) < N); // bonds [E, E + N): transverse field
+                const uint32_t own = __builtin_amdgcn_mbcnt_hi((uint32_t)(cutm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cutm[j], cutnext));
                 const uint32_t idin = (j & 1) ? (id2[j / 2] >> 16) : (id2[j / 2] & 0xFFFFu);
                 f1[j] = LDS16B(par_b + 2u * idin);
-                f2[j] = 0u;
-                if (iscut[j]) f2[j] = LDS16B(par_b + 2u * own); // the segment the cut opens
-                cutnext += (uint32_t)popc64(cutm);
+                f2[j] = LDS16B(par_b + 2u * own); // the segment a cut opens
+                cutnext += (uint32_t)popc64(cutm[j]);
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const bool two = (b1[j] - 1u) < B.E;
-                // two-site: all four bits follow the one cluster; cut: input with the incoming, output with the outgoing segment;
-                // longitudinal: both bits of its variable.  An empty slot carries f1 of the dummy id 0 only through the mask 0
-                const uint32_t flipmask = iscut[j] ? (f1[j] | (f2[j] << 2)) : (f1[j] ? (two ? 0xFu : 0x5u) : 0u);
-                wpend[j] = word[j] ? (word[j] ^ flipmask) : 0u;
+                // two-site: all four bits follow the one cluster; longitudinal: both bits of its variable; cut: input with the incoming,
+                // output with the outgoing segment
+                const uint32_t allbits = (((word[j] >> 4) - 1u) < B.E) ? 0xFu : 0x5u;
+                const uint32_t m_other = (0u - f1[j]) & allbits;
+                const uint32_t m_cut = f1[j] | (f2[j] << 2);
+                wpend[j] = word[j] ^ sel64(cutm[j], m_cut, m_other);
             }
         }
         if (pbeg < pend) {
