@@ -100,6 +100,13 @@ typedef struct isingmc_config {
     uint32_t ninteractions;
     double energy_offset;       /* added to -<n>/beta by isingmc_get_offset (sum of the offsets the caller absorbed,
                                    Qmc::make_interaction_and_offset) */
+    /* Per-replica fields, only with ISINGMC_CFG_PER_REPLICA_J (every replica then runs on its own bond table): [R] transverse
+     * fields / [R] longitudinal fields replacing `transverse` / `longitudinal`; NULL = the scalar for every replica.  The
+     * longitudinal fields must be all zero (|h| <= DBL_EPSILON) or all non-zero: the bond numbering (qmc_ising.rs:228-246) is
+     * common to a batch.  Parallel tempering between graphs whose Gamma and h differ (GraphWeights::relative_weight,
+     * tempering_traits.rs:126-155) builds on this: the tables belong to the temperature slot. */
+    const double *transverse_r;
+    const double *longitudinal_r;
 } isingmc_config;
 
 /* One interaction: k = 1 or 2 variables and the 4^k matrix of the reference (Interaction::at, qmc_runner.rs:573-612):

@@ -51,7 +51,8 @@ class _Config(C.Structure):
                 ("device", C.c_int32), ("init_state", C.POINTER(C.c_uint8)),
                 ("waves_per_replica", C.c_uint32), ("slots_per_lane", C.c_uint32), ("flags", C.c_uint32),
                 ("lds_uf_ids_limit", C.c_uint32), ("waves_offdiag", C.c_uint32),
-                ("interactions", C.c_void_p), ("ninteractions", C.c_uint32), ("energy_offset", C.c_double)]
+                ("interactions", C.c_void_p), ("ninteractions", C.c_uint32), ("energy_offset", C.c_double),
+                ("transverse_r", C.POINTER(C.c_double)), ("longitudinal_r", C.POINTER(C.c_double))]
 
 
 _PT_SENDRECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
@@ -211,11 +212,13 @@ class QmcIsingGraph:
 
     def __init__(self, edges, transverse, longitudinal, cutoff, seed, state=None, nreplicas=1,
                  capacity=None, replica_offset=0, device=-1, waves_per_replica=0, slots_per_lane=0,
-                 cfg_flags=0, lds_uf_ids_limit=0, waves_offdiag=0, couplings=None, nvars=None):
+                 cfg_flags=0, lds_uf_ids_limit=0, waves_offdiag=0, couplings=None, nvars=None, transverse_r=None, longitudinal_r=None):
         """`couplings` (float64 [nreplicas][nedges]) gives every replica its own J values on the same graph (disorder
         realisations, BASELINE configs[4]); the J of `edges` is then ignored.  `nvars` overrides the reference's
         "largest edge index + 1" (qmc_ising.rs:92) and allows graphs without any edge (the reference's RVB fixtures,
-        tests/check_rvb_crash.rs:68-110, run on isolated variables)."""
+        tests/check_rvb_crash.rs:68-110, run on isolated variables).  `transverse_r` / `longitudinal_r` (float64 [nreplicas]) give
+        every replica its own fields (per-replica Hamiltonians, e.g. tempering between graphs that differ in Gamma and h:
+        tempering_traits.rs:126-155); they imply per-replica bond tables like `couplings`."""
         lib = load_library()
         self._lib = lib
         self._h = None
@@ -231,6 +234,15 @@ class QmcIsingGraph:
             if js.shape != (int(nreplicas), len(ed)):
                 raise IsingMcError(-1, "couplings must have shape [nreplicas][nedges]")
             cfg_flags = int(cfg_flags) | CFG_PER_REPLICA_J
+        self.transverse_r = self.longitudinal_r = None
+        if transverse_r is not None or longitudinal_r is not None:
+            if couplings is None:  # per-replica tables with the same couplings everywhere
+                js = np.ascontiguousarray(np.broadcast_to(js, (int(nreplicas), len(ed))).copy())
+                cfg_flags = int(cfg_flags) | CFG_PER_REPLICA_J
+            if transverse_r is not None:
+                self.transverse_r = np.ascontiguousarray(np.broadcast_to(np.asarray(transverse_r, dtype=np.float64), (int(nreplicas),)).copy())
+            if longitudinal_r is not None:
+                self.longitudinal_r = np.ascontiguousarray(np.broadcast_to(np.asarray(longitudinal_r, dtype=np.float64), (int(nreplicas),)).copy())
         self.edges, self.J = ed, js
         if capacity is None:
             capacity = max(int(cutoff), 64)
@@ -248,7 +260,9 @@ class QmcIsingGraph:
                       replica_offset=int(replica_offset), device=int(device),
                       init_state=_ptr(init, C.c_uint8) if init is not None else None,
                       waves_per_replica=int(waves_per_replica), slots_per_lane=int(slots_per_lane),
-                      flags=int(cfg_flags), lds_uf_ids_limit=int(lds_uf_ids_limit), waves_offdiag=int(waves_offdiag))
+                      flags=int(cfg_flags), lds_uf_ids_limit=int(lds_uf_ids_limit), waves_offdiag=int(waves_offdiag),
+                      transverse_r=_ptr(self.transverse_r, C.c_double) if self.transverse_r is not None else None,
+                      longitudinal_r=_ptr(self.longitudinal_r, C.c_double) if self.longitudinal_r is not None else None)
         h = C.c_void_p()
         rc = lib.isingmc_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -607,7 +607,15 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     if (hipSetDevice(dev) != hipSuccess) { b->err = "hipSetDevice failed"; return fail(ISINGMC_ENODEVICE); }
 
     DevBatch &D = b->dev;
-    const bool has_long = !generic && std::fabs(cfg->longitudinal) > DBL_EPSILON; // qmc_ising.rs:230
+    const bool perJ_cfg = (cfg->flags & ISINGMC_CFG_PER_REPLICA_J) != 0;
+    if ((cfg->transverse_r || cfg->longitudinal_r) && (!perJ_cfg || generic)) { b->err = "per-replica fields need ISINGMC_CFG_PER_REPLICA_J (per-replica bond tables)"; return fail(ISINGMC_EINVAL); }
+    auto gamma_of = [&](uint32_t row) { return cfg->transverse_r ? cfg->transverse_r[row] : cfg->transverse; };
+    auto hfield_of = [&](uint32_t row) { return cfg->longitudinal_r ? cfg->longitudinal_r[row] : cfg->longitudinal; };
+    const bool has_long = !generic && std::fabs(hfield_of(0)) > DBL_EPSILON; // qmc_ising.rs:230
+    for (uint32_t r = 0; !generic && r < (perJ_cfg ? cfg->nreplicas : 1u); ++r) {
+        if (!(gamma_of(r) >= 0.0) || !std::isfinite(gamma_of(r)) || !std::isfinite(hfield_of(r))) { b->err = "fields must be finite, transverse field >= 0"; return fail(ISINGMC_EINVAL); }
+        if ((std::fabs(hfield_of(r)) > DBL_EPSILON) != has_long) { b->err = "longitudinal fields must be all zero or all non-zero within a batch"; return fail(ISINGMC_EINVAL); }
+    }
     b->generic = generic;
     D.R = cfg->nreplicas; D.N = cfg->nvars; D.E = generic ? 0u : cfg->nedges;
     D.Nb = generic ? cfg->ninteractions : cfg->nedges + cfg->nvars + (has_long ? cfg->nvars : 0);
@@ -672,17 +680,18 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
             t0[e].w = 2.0 * std::fabs(J);
             off += std::fabs(J);
         }
+        const double gam = gamma_of(hI), hl = hfield_of(hI);
         for (uint32_t v = 0; v < D.N; ++v) {
             BondRec &t = t0[D.E + v];
-            t.a_info = v | (SSE_BOND_TRANSVERSE << SSE_INFO_SHIFT); t.c = SSE_NO_VAR; t.w = cfg->transverse;
+            t.a_info = v | (SSE_BOND_TRANSVERSE << SSE_INFO_SHIFT); t.c = SSE_NO_VAR; t.w = gam;
         }
         if (has_long)
             for (uint32_t v = 0; v < D.N; ++v) {
                 BondRec &t = t0[D.E + D.N + v];
-                t.a_info = v | ((SSE_BOND_LONGITUDINAL | (cfg->longitudinal > 0.0 ? SSE_BOND_PREF_BIT : 0u)) << SSE_INFO_SHIFT);
-                t.c = SSE_NO_VAR; t.w = 2.0 * std::fabs(cfg->longitudinal);
+                t.a_info = v | ((SSE_BOND_LONGITUDINAL | (hl > 0.0 ? SSE_BOND_PREF_BIT : 0u)) << SSE_INFO_SHIFT);
+                t.c = SSE_NO_VAR; t.w = 2.0 * std::fabs(hl);
             }
-        const double offset = off + (double)D.N * (cfg->transverse + std::fabs(cfg->longitudinal));
+        const double offset = off + (double)D.N * (gam + std::fabs(hl));
         if (hI == 0) b->offset = offset;
         if (perJ) b->offsets[hI] = offset;
         double c = 0.0;
@@ -1002,6 +1011,14 @@ static void host_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// f64::powi as Rust lowers it (compiler-rt __powidf2): squaring sequence, reciprocal for negative exponents
+static double host_powi(double x, int64_t n) {
+    uint64_t m = n < 0 ? (uint64_t)(-n) : (uint64_t)n;
+    double r = 1.0;
+    while (m) { if (m & 1u) r *= x; x *= x; m >>= 1; }
+    return n < 0 ? 1.0 / r : r;
+}
+
 int isingmc_pt_decide(uint64_t seed, uint64_t step, uint32_t nchains, uint32_t ntemps, const double *betas,
                       const uint32_t *n_of_config, uint32_t *config_at, uint64_t *nswaps) {
     if (!betas || !n_of_config || !config_at || nchains == 0 || ntemps == 0) return ISINGMC_EINVAL;
@@ -1019,8 +1036,8 @@ int isingmc_pt_decide(uint64_t seed, uint64_t step, uint32_t nchains, uint32_t n
                 host_philox(ctr, key, o);
                 const double u = (double)o[0] * (1.0 / 4294967296.0);
                 uint32_t &ca = config_at[(size_t)t * nchains + chain], &cb = config_at[(size_t)(t + 1) * nchains + chain];
-                const double dn = (double)((int64_t)n_of_config[cb] - (int64_t)n_of_config[ca]);
-                if (std::pow(betas[t] / betas[t + 1], dn) > u) { // swap_on_chunks (:296-298), equal Hamiltonians
+                const int64_t dn = (int64_t)n_of_config[cb] - (int64_t)n_of_config[ca];
+                if (host_powi(betas[t] / betas[t + 1], dn) > u) { // swap_on_chunks (:296-298), equal Hamiltonians: f64::powi
                     const uint32_t tmp = ca; ca = cb; cb = tmp;
                     swaps++;
                 }
@@ -1241,6 +1258,8 @@ int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
 // temperature block, and no collective touches the sweep path.  The transport is RCCL point-to-point on device buffers when a
 // communicator is attached (isingmc_pt_attach_nccl), otherwise the caller's host-staged sendrecv (tests: two ranks on one GPU).
 #include <dlfcn.h>
+#include <rccl/rccl.h> // types and enum values only (ncclUint32, ncclMax, ncclUniqueId): the library itself is dlopen()ed on first use
+static_assert(sizeof(ncclUniqueId) == sizeof(isingmc_nccl_id), "isingmc_nccl_id must carry an ncclUniqueId");
 
 struct PtState {
     uint32_t ntemps = 0, nchains = 0, rank = 0, world = 1, tper = 0;
@@ -1260,6 +1279,7 @@ struct PtState {
     int (*p_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*p_init)(void **, int, isingmc_nccl_id, int) = nullptr;
     int (*p_destroy)(void *) = nullptr;
+    uint32_t *d_items = nullptr; // [3 * nchains] accepted boundary swaps of one turn: (replica, word offset, cutoff)
     uint32_t *d_small = nullptr; // [4][nchains] staging of the boundary operator counts / cutoffs on the device (RCCL path)
     // different Hamiltonians per temperature (per-replica couplings): J rows of the neighbouring ranks' boundary slots
     bool hams_differ = false;
@@ -1275,7 +1295,7 @@ static void pt_free(isingmc_batch *b) {
     if (!b->pt) return;
     PtState *P = b->pt;
     if (P->comm && P->p_destroy) (void)P->p_destroy(P->comm);
-    for (void *q : {(void *)P->d_rid, (void *)P->d_ham_row, (void *)P->d_small, (void *)P->d_counts, (void *)P->d_pack_s, (void *)P->d_pack_r})
+    for (void *q : {(void *)P->d_rid, (void *)P->d_ham_row, (void *)P->d_small, (void *)P->d_counts, (void *)P->d_pack_s, (void *)P->d_pack_r, (void *)P->d_items})
         if (q) (void)hipFree(q);
     delete P;
     b->pt = nullptr;
@@ -1325,12 +1345,34 @@ static double pt_powi(double x, uint32_t n) { // x^n by squaring (the oracle use
     while (n) { if (n & 1u) r *= x; x *= x; n >>= 1; }
     return r;
 }
-// GraphWeights::relative_weight (tempering_traits.rs:126-155) for couplings that differ between temperature slots (the fields
-// are common to a batch): product over the edges of (J_to / J_from)^count, in edge order
-static double pt_relative_weight(const double *J_from, const double *J_to, const uint32_t *counts, uint32_t E) {
+// f64::powi for the swap test's temperature factor (tempering_container.rs:296): the same squaring sequence, the reciprocal
+// for a negative exponent (compiler-rt __powidf2, which Rust's powi lowers to)
+static double pt_powi_signed(double x, int64_t n) { return n < 0 ? 1.0 / pt_powi(x, (uint32_t)(-n)) : pt_powi(x, (uint32_t)n); }
+// GraphWeights::relative_weight (tempering_traits.rs:126-155): the weight of a configuration under the Hamiltonian `to` relative
+// to the one it lives in (`from`).  Rows are [E] couplings, then Gamma, then h: product over the edges of (J_to / J_from)^count in
+// edge order, times (Gamma_to / Gamma_from)^(transverse ops), times (h_to / h_from)^(longitudinal ops) when h_from != 0
+static double pt_relative_weight(const double *from, const double *to, const uint32_t *counts, uint32_t E, uint32_t N, bool has_long) {
     double w = 1.0;
-    for (uint32_t e = 0; e < E; ++e) w *= pt_powi(J_to[e] / J_from[e], counts[e]);
+    for (uint32_t e = 0; e < E; ++e) w *= pt_powi(to[e] / from[e], counts[e]);
+    uint32_t tc = 0;
+    for (uint32_t v = 0; v < N; ++v) tc += counts[E + v];
+    w *= pt_powi(to[E] / from[E], tc);
+    if (has_long && std::fabs(from[E + 1]) > DBL_EPSILON) {
+        uint32_t lc = 0;
+        for (uint32_t v = 0; v < N; ++v) lc += counts[E + N + v];
+        w *= pt_powi(to[E + 1] / from[E + 1], lc);
+    }
     return w;
+}
+
+// the Hamiltonian of bond-table row `row` as relative_weight needs it: J of every edge (weight 2|J|, "prefers aligned" = J < 0),
+// Gamma (weight of the transverse bonds), h (weight 2|h|, "prefers up" = h > 0; 0 without longitudinal bonds)
+static void pt_ham_row(const isingmc_batch *b, uint32_t row, double *out) {
+    const uint32_t E = b->dev.E, N = b->dev.N, Nb = b->dev.Nb;
+    const BondRec *t0 = b->bonds_host.data() + (size_t)row * Nb;
+    for (uint32_t e = 0; e < E; ++e) out[e] = (((t0[e].a_info >> (SSE_INFO_SHIFT + 2)) & 1u) ? -0.5 : 0.5) * t0[e].w;
+    out[E] = t0[E].w;
+    out[E + 1] = b->dev.has_long ? (((t0[E + N].a_info >> (SSE_INFO_SHIFT + 2)) & 1u) ? 0.5 : -0.5) * t0[E + N].w : 0.0;
 }
 
 static int pt_exchange_small(isingmc_batch *b, int peer, const uint32_t *s, uint32_t *r, size_t count) {
@@ -1339,7 +1381,7 @@ static int pt_exchange_small(isingmc_batch *b, int peer, const uint32_t *s, uint
     if (P->comm) { // RCCL point-to-point on device buffers, one group call
         uint32_t *ds = P->d_small, *dr = P->d_small + count;
         HIP_TRY(b, hipMemcpyAsync(ds, s, 4 * count, hipMemcpyHostToDevice, b->stream));
-        if (P->p_gstart() || P->p_send(ds, count, /*ncclUint32*/ 3, peer, P->comm, b->stream) || P->p_recv(dr, count, 3, peer, P->comm, b->stream) || P->p_gend()) {
+        if (P->p_gstart() || P->p_send(ds, count, (int)ncclUint32, peer, P->comm, b->stream) || P->p_recv(dr, count, (int)ncclUint32, peer, P->comm, b->stream) || P->p_gend()) {
             b->err = "RCCL send/recv failed"; return ISINGMC_ENODEVICE;
         }
         HIP_TRY(b, hipMemcpyAsync(r, dr, 4 * count, hipMemcpyDeviceToHost, b->stream));
@@ -1373,6 +1415,7 @@ int isingmc_pt_create(isingmc_batch *b, const isingmc_pt_layout *lay) {
     HIP_TRY(b, hipMemcpy(P->d_rid, P->rid.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
     b->dev.rid = P->d_rid;
     HIP_TRY(b, hipMalloc((void **)&P->d_small, 4 * 4 * (size_t)(P->nchains * 2 + 2)));
+    HIP_TRY(b, hipMalloc((void **)&P->d_items, 4 * 3 * (size_t)P->nchains));
     P->pack_cap_words = (size_t)P->nchains * (PT_HDR + b->dev.nwords + 2 * SSE_MAX_CHUNKS + b->dev.cap);
     HIP_TRY(b, hipMalloc((void **)&P->d_pack_s, 4 * P->pack_cap_words));
     HIP_TRY(b, hipMalloc((void **)&P->d_pack_r, 4 * P->pack_cap_words));
@@ -1385,16 +1428,11 @@ int isingmc_pt_create(isingmc_batch *b, const isingmc_pt_layout *lay) {
         HIP_TRY(b, hipMemcpy(P->d_ham_row, b->ham_row_host.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
         b->dev.ham_row = P->d_ham_row;
         HIP_TRY(b, hipMalloc((void **)&P->d_counts, 4 * (size_t)R * b->dev.Nb));
-        const uint32_t E = b->dev.E, K = P->nchains;
-        auto Jrow = [&](uint32_t row, std::vector<double> &out, size_t at) { // J from the bond table: weight 2|J|, "prefers aligned" = J < 0
-            for (uint32_t e = 0; e < E; ++e) {
-                const BondRec &br = b->bonds_host[(size_t)row * b->dev.Nb + e];
-                out[at + e] = (((br.a_info >> (SSE_INFO_SHIFT + 2)) & 1u) ? -0.5 : 0.5) * br.w;
-            }
-        };
-        std::vector<double> first((size_t)K * E), last((size_t)K * E);
-        for (uint32_t k = 0; k < K; ++k) { Jrow(k, first, (size_t)k * E); Jrow((tper - 1) * K + k, last, (size_t)k * E); }
-        P->J_prev_last.assign((size_t)K * E, 0.0); P->J_next_first.assign((size_t)K * E, 0.0);
+        const uint32_t E = b->dev.E, K = P->nchains, HS = E + 2; // a Hamiltonian row: [E] couplings, Gamma, h
+        auto Jrow = [&](uint32_t row, std::vector<double> &out, size_t at) { pt_ham_row(b, row, out.data() + at); };
+        std::vector<double> first((size_t)K * HS), last((size_t)K * HS);
+        for (uint32_t k = 0; k < K; ++k) { Jrow(k, first, (size_t)k * HS); Jrow((tper - 1) * K + k, last, (size_t)k * HS); }
+        P->J_prev_last.assign((size_t)K * HS, 0.0); P->J_next_first.assign((size_t)K * HS, 0.0);
         if (P->world > 1) {
             const int prev = (int)P->rank - 1, next = (int)P->rank + 1;
             if (prev >= 0 && P->tr.sendrecv(P->tr.ctx, prev, first.data(), 8 * first.size(), P->J_prev_last.data(), 8 * first.size())) { b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
@@ -1501,7 +1539,7 @@ int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps) {
     if (P->world > 1) {
         if (P->comm) {
             HIP_TRY(b, hipMemcpyAsync(P->d_small, maxcut.data(), 4 * (size_t)K, hipMemcpyHostToDevice, b->stream));
-            if (P->p_allreduce(P->d_small, P->d_small, K, /*ncclUint32*/ 3, /*ncclMax*/ 2, P->comm, b->stream)) { b->err = "ncclAllReduce failed"; return ISINGMC_ENODEVICE; }
+            if (P->p_allreduce(P->d_small, P->d_small, K, (int)ncclUint32, (int)ncclMax, P->comm, b->stream)) { b->err = "ncclAllReduce failed"; return ISINGMC_ENODEVICE; }
             HIP_TRY(b, hipMemcpyAsync(maxcut.data(), P->d_small, 4 * (size_t)K, hipMemcpyDeviceToHost, b->stream));
             HIP_TRY(b, hipStreamSynchronize(b->stream));
         } else if (P->tr.allreduce_max_u32(P->tr.ctx, maxcut.data(), K)) { b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
@@ -1513,16 +1551,16 @@ int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps) {
     }
     HIP_TRY(b, hipMemcpy(b->dev.cutoff, cut.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
     std::vector<uint32_t> counts; // bond counts of every local configuration (only when the Hamiltonians differ between temperatures)
-    auto Jrow_local = [&](uint32_t row, uint32_t e) { const BondRec &br = b->bonds_host[(size_t)row * Nb + e]; return (((br.a_info >> (SSE_INFO_SHIFT + 2)) & 1u) ? -0.5 : 0.5) * br.w; };
-    std::vector<double> Ja(E), Jb(E);
+    const uint32_t HS = E + 2;
+    std::vector<double> Ja(HS), Jb(HS);
     // relative weight of local replica r (at local slot ls) towards the Hamiltonian of the slot above (+1) or below (-1)
     auto relw = [&](uint32_t r, uint32_t ls, int dir) -> double {
         if (!P->hams_differ) return 1.0;
         const uint32_t k = ls % K, tl = ls / K;
-        for (uint32_t e = 0; e < E; ++e) Ja[e] = Jrow_local(ls, e);
-        if (dir > 0) { if (tl + 1 < tper) for (uint32_t e = 0; e < E; ++e) Jb[e] = Jrow_local(ls + K, e); else for (uint32_t e = 0; e < E; ++e) Jb[e] = P->J_next_first[(size_t)k * E + e]; }
-        else { if (tl > 0) for (uint32_t e = 0; e < E; ++e) Jb[e] = Jrow_local(ls - K, e); else for (uint32_t e = 0; e < E; ++e) Jb[e] = P->J_prev_last[(size_t)k * E + e]; }
-        return pt_relative_weight(Ja.data(), Jb.data(), counts.data() + (size_t)r * Nb, E);
+        pt_ham_row(b, ls, Ja.data());
+        if (dir > 0) { if (tl + 1 < tper) pt_ham_row(b, ls + K, Jb.data()); else for (uint32_t e = 0; e < HS; ++e) Jb[e] = P->J_next_first[(size_t)k * HS + e]; }
+        else { if (tl > 0) pt_ham_row(b, ls - K, Jb.data()); else for (uint32_t e = 0; e < HS; ++e) Jb[e] = P->J_prev_last[(size_t)k * HS + e]; }
+        return pt_relative_weight(Ja.data(), Jb.data(), counts.data() + (size_t)r * Nb, E, b->dev.N, b->dev.has_long != 0u);
     };
     // order coin per chain (gen_bool(0.5), :140)
     const uint32_t key[2] = {(uint32_t)P->seed, (uint32_t)(P->seed >> 32)};
@@ -1538,8 +1576,7 @@ int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps) {
         uint32_t o[4];
         host_philox(ctr, key, o);
         const double u = (double)o[0] * (1.0 / 4294967296.0);
-        const double dn = (double)((int64_t)nb2 - (int64_t)na);
-        double p = std::pow(P->betas[t] / P->betas[t + 1], dn); // swap_on_chunks (:296-298)
+        double p = pt_powi_signed(P->betas[t] / P->betas[t + 1], (int64_t)nb2 - (int64_t)na); // swap_on_chunks (:296-298): powi
         if (P->hams_differ) p *= ra * rb;
         return p > u;
     };
@@ -1612,24 +1649,22 @@ int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps) {
             const int peer = up ? next : prev;
             if (peer < 0 || items.empty()) continue;
             const uint32_t nitems = (uint32_t)(items.size() / 3);
-            uint32_t *d_it = nullptr;
-            HIP_TRY(b, hipMalloc((void **)&d_it, 4 * items.size()));
+            uint32_t *d_it = P->d_items; // (at most one item per chain and turn)
             HIP_TRY(b, hipMemcpyAsync(d_it, items.data(), 4 * items.size(), hipMemcpyHostToDevice, b->stream));
             hipLaunchKernelGGL(pt_pack_kernel, dim3(nitems), dim3(256), 0, b->stream, b->dev, P->d_rid, d_it, P->d_pack_s);
             if (P->comm) {
-                if (P->p_gstart() || P->p_send(P->d_pack_s, words, 3, peer, P->comm, b->stream) || P->p_recv(P->d_pack_r, words, 3, peer, P->comm, b->stream) || P->p_gend()) {
-                    (void)hipFree(d_it); b->err = "RCCL send/recv failed"; return ISINGMC_ENODEVICE;
+                if (P->p_gstart() || P->p_send(P->d_pack_s, words, (int)ncclUint32, peer, P->comm, b->stream) || P->p_recv(P->d_pack_r, words, (int)ncclUint32, peer, P->comm, b->stream) || P->p_gend()) {
+                    b->err = "RCCL send/recv failed"; return ISINGMC_ENODEVICE;
                 }
             } else {
                 P->h_pack_s.resize(words); P->h_pack_r.resize(words);
                 HIP_TRY(b, hipMemcpyAsync(P->h_pack_s.data(), P->d_pack_s, 4 * words, hipMemcpyDeviceToHost, b->stream));
                 HIP_TRY(b, hipStreamSynchronize(b->stream));
-                if (P->tr.sendrecv(P->tr.ctx, peer, P->h_pack_s.data(), 4 * words, P->h_pack_r.data(), 4 * words)) { (void)hipFree(d_it); b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
+                if (P->tr.sendrecv(P->tr.ctx, peer, P->h_pack_s.data(), 4 * words, P->h_pack_r.data(), 4 * words)) { b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
                 HIP_TRY(b, hipMemcpyAsync(P->d_pack_r, P->h_pack_r.data(), 4 * words, hipMemcpyHostToDevice, b->stream));
             }
             hipLaunchKernelGGL(pt_unpack_kernel, dim3(nitems), dim3(256), 0, b->stream, b->dev, P->d_rid, d_it, P->d_pack_r);
             HIP_TRY(b, hipStreamSynchronize(b->stream));
-            (void)hipFree(d_it);
         }
         if (!items_next.empty() || !items_prev.empty()) HIP_TRY(b, hipMemcpy(P->rid.data(), P->d_rid, 4 * (size_t)R, hipMemcpyDeviceToHost));
     }

@@ -9,8 +9,14 @@ reference struct would hold for the same configuration.  The engine stores no li
 `from_serde` installs such a dict into a replica (ops, p=0 state, cutoff), ignoring the link fields (FastOps::new_from_ops does
 the same, fast_ops.rs:80-174).
 
-Status: layout follows the struct definitions field by field; no file produced by the Rust crate exists in this project to
-compare with (no Rust toolchain) — byte-level compatibility with serde_json output is therefore unpinned.
+The op manager's allocator is the default `DefaultFastOpAllocator` (FastOps = FastOpsTemplate<FastOp>, fast_ops.rs:18,35-49): nine
+`Allocator<..>` members (fast_op_alloc.rs:29-39), each serialised as {instances: <length, u64: util/allocator.rs:31-38,142-162>,
+gen_more}; a graph at rest has every pooled instance returned, so the lengths are the `max_in_flight` values of its `Default`
+(fast_op_alloc.rs:43-56).
+
+Status: FIELD NAMES AND NESTING of SerializeQmcGraph as read off the struct definitions (tests/test_abi_cpu.py walks a dict against a
+schema written from those definitions); no file produced by the Rust crate exists in this project to compare with (no Rust toolchain,
+SURVEY.md §8c) — byte-level compatibility with serde_json output is therefore unpinned.
 """
 import numpy as np
 
@@ -25,11 +31,25 @@ def _bond_vars(graph, bond):
     return [int((bond - ne) % graph.nvars)]
 
 
-def to_serde(graph, r=0):
+# DefaultFastOpAllocator::default() (fast_op_alloc.rs:43-56): pooled instances per member
+DEFAULT_ALLOCATOR_POOLS = (("usize_alloc", 10), ("bool_alloc", 2), ("opside_alloc", 1), ("leg_alloc", 1), ("option_usize_alloc", 4),
+                           ("f64_alloc", 1), ("bond_container_alloc", 2), ("bond_container_varpos_alloc", 2), ("binary_heap_alloc", 1))
+
+
+def classical_bonds(graph):
+    """make_classical_bonds (qmc_ising.rs:421-432): for every variable the bonds (edge numbers) it belongs to, in edge order."""
+    lookup = [[] for _ in range(graph.nvars)]
+    for bond, (a, b) in enumerate(graph.edges):
+        lookup[int(a)].append(bond)
+        lookup[int(b)].append(bond)
+    return lookup
+
+
+def to_serde(graph, r=0, total_rvb_successes=0, rvb_clusters_counted=0):
     words = graph.export_ops(r)
     state = graph.state_ref()[r]
     nvars, ne = graph.nvars, len(graph.edges)
-    has_long = abs(graph.longitudinal) > np.finfo(float).eps
+    has_long = abs(float(graph.longitudinal_r[r]) if getattr(graph, "longitudinal_r", None) is not None else graph.longitudinal) > np.finfo(float).eps
     nbonds = ne + nvars + (nvars if has_long else 0)
     nodes = [None] * len(words)
     last_p, first_p = None, None
@@ -66,14 +86,20 @@ def to_serde(graph, r=0):
                 for v in range(nvars)]
     ops_n = int(np.count_nonzero(words))
     manager = {"ops": nodes, "n": ops_n, "p_ends": None if first_p is None else [first_p, last_p], "var_ends": var_ends,
-               "bond_counters": counters, "alloc": {"alloc": None}}  # SwitchableFastOpAllocator without a backing pool
+               "bond_counters": counters,
+               "alloc": {name: {"instances": n, "gen_more": False} for name, n in DEFAULT_ALLOCATOR_POOLS}}
     J = np.asarray(graph.J)
     Jr = J[r] if J.ndim == 2 else J
     edges = [[[int(a), int(b)], float(j)] for (a, b), j in zip(graph.edges, Jr)]
     offset = float(graph.get_offsets()[r])
-    return {"edges": edges, "transverse": graph.transverse, "longitudinal": graph.longitudinal, "state": [bool(s) for s in state],
+    run_rvb = bool(graph._flags & 8)
+    gam = float(graph.transverse_r[r]) if getattr(graph, "transverse_r", None) is not None else graph.transverse
+    hl = float(graph.longitudinal_r[r]) if getattr(graph, "longitudinal_r", None) is not None else graph.longitudinal
+    # (set_run_rvb builds classical_bonds, qmc_ising.rs:435-447, and timestep unwraps it when run_rvb_steps is set, :705-708)
+    return {"edges": edges, "transverse": gam, "longitudinal": hl, "state": [bool(s) for s in state],
             "cutoff": int(len(words)), "op_manager": manager, "total_energy_offset": offset, "nvars": nvars,
-            "run_rvb_steps": bool(graph._flags & 8), "classical_bonds": None, "total_rvb_successes": 0, "rvb_clusters_counted": 0,
+            "run_rvb_steps": run_rvb, "classical_bonds": classical_bonds(graph) if run_rvb else None,
+            "total_rvb_successes": int(total_rvb_successes), "rvb_clusters_counted": int(rvb_clusters_counted),
             "bond_weights": None}
 
 
@@ -81,9 +107,17 @@ def from_serde(graph, d, r=0):
     """Install the configuration of a SerializeQmcGraph dict into replica r (same model required)."""
     if int(d["nvars"]) != graph.nvars or len(d["edges"]) != len(graph.edges):
         raise ValueError("serialized graph belongs to a different model")
-    for (vs, j), (a, b) in zip(d["edges"], graph.edges):
+    J = np.asarray(graph.J)
+    Jr = J[r] if J.ndim == 2 else J
+    for (vs, j), (a, b), jg in zip(d["edges"], graph.edges, Jr):
         if [int(a), int(b)] != [int(x) for x in vs]:
             raise ValueError("serialized graph has different edges")
+        if float(j) != float(jg):
+            raise ValueError("serialized graph has different couplings")
+    gam = float(graph.transverse_r[r]) if getattr(graph, "transverse_r", None) is not None else graph.transverse
+    hl = float(graph.longitudinal_r[r]) if getattr(graph, "longitudinal_r", None) is not None else graph.longitudinal
+    if float(d["transverse"]) != gam or float(d["longitudinal"]) != hl:
+        raise ValueError("serialized graph has different fields")
     ops = d["op_manager"]["ops"] if d.get("op_manager") else []
     words = np.zeros(max(int(d["cutoff"]), len(ops)), dtype=np.uint32)
     for p, node in enumerate(ops):

@@ -654,6 +654,14 @@ void ora_reset_accumulators(ora_replica *r) { memset(r->acc, 0, sizeof(r->acc));
  *   3. each pair draws one uniform u and swaps iff (beta_a/beta_b)^(n_b - n_a) > u (:255, :296-298).
  * Philox: tag PT, replica field = chain, epoch = step; index 0 = the order coin, index 1+t = the pair whose
  * lower slot is t.  Returns the number of swaps. */
+/* f64::powi (tempering_container.rs:296) as Rust lowers it (compiler-rt __powidf2): repeated squaring, reciprocal for a
+ * negative exponent */
+static double powi_signed(double x, int64_t n) {
+    uint64_t m = n < 0 ? (uint64_t)(-n) : (uint64_t)n;
+    double r = 1.0;
+    while (m) { if (m & 1u) r *= x; x *= x; m >>= 1; }
+    return n < 0 ? 1.0 / r : r;
+}
 uint64_t ora_pt_step(ora_replica **by_slot, const double *betas, uint32_t ntemps, uint64_t seed, uint32_t chain,
                      uint64_t step) {
     if (ntemps <= 1) return 0;
@@ -674,7 +682,7 @@ uint64_t ora_pt_step(ora_replica **by_slot, const double *betas, uint32_t ntemps
             ora_philox4x32_10(ctr, key, o);
             const double u = u01(o[0]);
             ora_replica *ga = by_slot[t], *gb = by_slot[t + 1];
-            const double p_swap = pow(betas[t] / betas[t + 1], (double)((int64_t)gb->n - (int64_t)ga->n));
+            const double p_swap = powi_signed(betas[t] / betas[t + 1], (int64_t)gb->n - (int64_t)ga->n);
             if (p_swap > u) {
                 by_slot[t] = gb;
                 by_slot[t + 1] = ga;

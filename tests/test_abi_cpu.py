@@ -1,6 +1,7 @@
 """CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
 include/isingmc_hip.h declares, and fails loudly (no CPU fallback) when no HIP device exists."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -29,8 +30,9 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_config_struct_layout_matches_header():
     import isingmontecarlo_amd as im
-    # 4 u32, 2 pointers, 2 doubles, 2 u32, u64, u32, i32, pointer, 5 u32 (+4 padding), pointer, u32 (+4), double -> 128 bytes on LP64
-    assert C.sizeof(im._Config) == 128 and C.sizeof(im._Interaction) == 24 and im._Interaction.mat.offset == 16
+    # 4 u32, 2 pointers, 2 doubles, 2 u32, u64, u32, i32, pointer, 5 u32 (+4 padding), pointer, u32 (+4), double, 2 pointers -> 144 bytes on LP64
+    assert C.sizeof(im._Config) == 144 and C.sizeof(im._Interaction) == 24 and im._Interaction.mat.offset == 16
+    assert im._Config.transverse_r.offset == 128 and im._Config.longitudinal_r.offset == 136
     assert im._Config.seed.offset == 56 and im._Config.init_state.offset == 72
 
 
@@ -160,3 +162,65 @@ def test_header_is_plain_c_and_matches_the_python_mirror(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"), str(src), "-o", exe])
     a, b = (int(x) for x in subprocess.check_output([exe], text=True).split())
     assert a == C.sizeof(im._Config) and b == C.sizeof(im._Interaction)
+
+
+def test_serde_dict_follows_the_reference_struct_definitions():
+    """The dict of serde_format.to_serde walked against a schema written by hand from the Rust struct definitions (field names,
+    nesting, Option / tuple / enum shapes as serde_json writes them): SerializeQmcGraph qmc_ising.rs:1010-1028, FastOpsTemplate
+    fast_ops.rs:35-49, FastOpNodeTemplate :181-190, BasicOp op_container.rs:224-237, OpType :165-173, PRel directed_loop.rs:12-17,
+    DefaultFastOpAllocator fast_op_alloc.rs:29-39, Allocator util/allocator.rs:31-38 (instances as its length).  No GPU: the
+    graph is a stand-in that hands out a hand-built op-string."""
+    import isingmontecarlo_amd as im
+    from isingmontecarlo_amd.serde_format import to_serde
+
+    class Stub:  # what to_serde asks of a graph
+        nvars = 3
+        edges = np.array([[0, 1], [1, 2]], dtype=np.uint32)
+        J = np.array([1.0, -0.5])
+        transverse, longitudinal = 0.7, 0.2
+        _flags = 8  # run_rvb
+        transverse_r = longitudinal_r = None
+        def export_ops(self, r):  # two-site diagonal, empty, transverse off-diagonal on var 1, longitudinal diagonal on var 2
+            return np.array([im.op_make(0, 0b10, 0b10), 0, im.op_make(2 + 1, 0, 1), im.op_make(2 + 3 + 2, 1, 1)], dtype=np.uint32)
+        def state_ref(self):
+            return np.array([[0, 1, 1]], dtype=np.uint8)
+        def get_offsets(self):
+            return np.array([4.2])
+
+    d = to_serde(Stub(), 0, total_rvb_successes=5, rvb_clusters_counted=9)
+    usize = lambda x: isinstance(x, int) and not isinstance(x, bool) and x >= 0
+    f64 = lambda x: isinstance(x, float)
+    boolean = lambda x: isinstance(x, bool)
+    opt = lambda f: (lambda x: x is None or f(x))
+    vec = lambda f: (lambda x: isinstance(x, list) and all(f(y) for y in x))
+    tup = lambda *fs: (lambda x: isinstance(x, list) and len(x) == len(fs) and all(f(y) for f, y in zip(fs, x)))
+    def struct(**fields):
+        def check(x):
+            assert isinstance(x, dict) and list(x.keys()) == list(fields.keys()), (list(x.keys()) if isinstance(x, dict) else x, list(fields.keys()))
+            for k, f in fields.items():
+                assert f(x[k]), (k, x[k])
+            return True
+        return check
+    prel = struct(p=usize, relv=usize)
+    optype = lambda x: isinstance(x, dict) and len(x) == 1 and (("Diagonal" in x and vec(boolean)(x["Diagonal"])) or
+                                                                ("Offdiagonal" in x and tup(vec(boolean), vec(boolean))(x["Offdiagonal"])))
+    basic_op = struct(vars=vec(usize), bond=usize, in_out=optype, constant=boolean)
+    node = struct(op=basic_op, previous_p=opt(usize), next_p=opt(usize), previous_for_vars=vec(opt(prel)), next_for_vars=vec(opt(prel)))
+    allocator = struct(instances=usize, gen_more=boolean)
+    alloc = struct(usize_alloc=allocator, bool_alloc=allocator, opside_alloc=allocator, leg_alloc=allocator, option_usize_alloc=allocator,
+                   f64_alloc=allocator, bond_container_alloc=allocator, bond_container_varpos_alloc=allocator, binary_heap_alloc=allocator)
+    manager = struct(ops=vec(opt(node)), n=usize, p_ends=opt(tup(usize, usize)), var_ends=vec(opt(tup(prel, prel))),
+                     bond_counters=vec(usize), alloc=alloc)
+    graph = struct(edges=vec(tup(vec(usize), f64)), transverse=f64, longitudinal=f64, state=opt(vec(boolean)), cutoff=usize,
+                   op_manager=opt(manager), total_energy_offset=f64, nvars=usize, run_rvb_steps=boolean,
+                   classical_bonds=opt(vec(vec(usize))), total_rvb_successes=usize, rvb_clusters_counted=usize,
+                   bond_weights=opt(struct(max_weight_and_cumulative=vec(tup(usize, f64, f64)))))
+    assert graph(json.loads(json.dumps(d)))
+    m = d["op_manager"]
+    assert m["n"] == 3 and m["p_ends"] == [0, 3] and m["ops"][1] is None and m["bond_counters"] == [1, 0, 0, 1, 0, 0, 0, 1]
+    assert m["ops"][0]["op"] == {"vars": [0, 1], "bond": 0, "in_out": {"Diagonal": [False, True]}, "constant": False}
+    assert m["ops"][2]["op"] == {"vars": [1], "bond": 3, "in_out": {"Offdiagonal": [[False], [True]]}, "constant": True}
+    assert m["ops"][2]["previous_for_vars"] == [{"p": 0, "relv": 1}] and m["ops"][0]["next_for_vars"] == [None, {"p": 2, "relv": 0}]
+    assert m["var_ends"] == [[{"p": 0, "relv": 0}, {"p": 0, "relv": 0}], [{"p": 0, "relv": 1}, {"p": 2, "relv": 0}], [{"p": 3, "relv": 0}, {"p": 3, "relv": 0}]]
+    assert m["alloc"]["usize_alloc"] == {"instances": 10, "gen_more": False} and m["alloc"]["binary_heap_alloc"]["instances"] == 1
+    assert d["run_rvb_steps"] and d["classical_bonds"] == [[0], [0, 1], [1]] and d["total_rvb_successes"] == 5 and d["rvb_clusters_counted"] == 9

@@ -486,6 +486,27 @@ def test_variable_autocorrelation_runs_on_sampled_states(oracle):
     assert pc.shape == (32,) and np.isfinite(pc).all() and 0.0 <= pc[0] <= 1.0 + 1e-9
 
 
+def test_variable_autocorrelation_values(oracle):
+    """Values, not shapes: the autocorrelation of the states the batch samples equals the defining O(T^2) circular sum over the
+    states the ORACLE samples on the same trajectory (autocorrelations.rs:99-133), through numpy's FFT and through hipFFT."""
+    from isingmontecarlo_amd.autocorrelations import variable_autocorrelation, direct_autocorrelation
+    edges = lat.two_d_ferro(4)
+    R, T, freq = 3, 48, 2
+    for device in (None, "cuda"):
+        g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 16, 1 << 11, 77, R)
+        ac = variable_autocorrelation(g, T * freq, 1.5, sampling_freq=freq, device=device)
+        samples = [[] for _ in range(R)]
+        for _ in range(T):
+            oracle.batch_timesteps(reps, freq, [1.5] * R)
+            for k, rep in enumerate(reps):
+                samples[k].append(rep.state().astype(np.float64) * 2.0 - 1.0)
+        assert_same(g, reps, "after autocorrelation sampling")
+        for k in range(R):
+            want = direct_autocorrelation(np.stack(samples[k]))
+            assert ac[k].shape == want.shape and np.abs(ac[k] - want).max() < 1e-10, (device, k, np.abs(ac[k] - want).max())
+            assert abs(want[0] - 1.0) < 1e-12 or (np.stack(samples[k]).std(axis=0) == 0).any()
+
+
 def test_bond_counts_match_the_oracle(oracle):
     """OpContainer::get_count (op_container.rs:129; fast_ops.rs:1281-1294) for every bond, straight through isingmc_get_bond_count."""
     edges = lat.one_d_periodic(6, -1.0)
@@ -781,3 +802,30 @@ def test_dedicated_cluster_kernel(oracle, name, edges, gamma, h, beta, cut0, nol
     for r, rep in enumerate(reps):
         assert np.array_equal(acc[r, :7], rep.accumulators()[:7]), f"accumulators differ r={r}: {acc[r]} vs {rep.accumulators()}"
     assert g.verify().all()
+
+
+def test_config0_sixteen_site_ring(oracle):
+    """BASELINE configs[0] / benches/end_to_end.rs:45-60 (one_d): the 16-site periodic chain J = +1, Gamma = 1, h = 0, beta = 1,
+    initial cutoff 16, 1000 warm-up timesteps then single timesteps — the reference's plumbing case, here as a parity case:
+    every timestep's operator words, states and counters against the oracle, through the default (trimmed / dedicated) kernels
+    and through the general ones."""
+    import isingmontecarlo_amd as im
+    edges = lat.one_d_periodic(16)
+    for cfgf in (0, im.CFG_NO_FAST_DIAG | im.CFG_NO_LEAN_CLUSTER):
+        g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 16, 4096, 1234, 3, cfg_flags=cfgf)
+        g.run(1000, 1.0)
+        oracle.batch_timesteps(reps, 1000, [1.0] * 3)
+        assert_same(g, reps, "one_d warm-up")
+        for it in range(20):
+            g.run(1, 1.0)
+            for rep in reps:
+                rep.timesteps(1, 1.0)
+            assert_same(g, reps, f"one_d timestep {it}")
+        acc = g.accumulators()
+        for r, rep in enumerate(reps):
+            assert np.array_equal(acc[r, :7], rep.accumulators()[:7])
+        assert g.verify().all()
+        # the energy estimator of the plumbing case is sane: E/N of the 16-site TFIM ring at beta = 1 lies between the classical
+        # bound and the high-temperature value
+        e = g.get_energy_for_average_n(acc[:, 0] / np.maximum(acc[:, 1], 1), 1.0) / 16.0
+        assert (-1.6 < e).all() and (e < -0.3).all(), e

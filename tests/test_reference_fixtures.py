@@ -208,3 +208,41 @@ def test_verify_rejects_corrupted_strings_on_the_device(oracle):
         rep = oracle.Replica(m, 512, len(words_r), 11, 0, st_r)
         rep.set_ops(words_r)
         assert rep.verify() == want
+
+
+def cluster_fixture_words(fx, nedges):
+    """The fixture's constant one-variable ops on the transverse-field bond of their variable (bond E + v); see cluster_note."""
+    return np.array([((nedges + o["vars"][0] + 1) << 4) | int(o["in"][0]) | (int(o["out"][0]) << 2) for o in fx["ops"]], dtype=np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lean", [True, False], ids=["dedicated_kernel", "general_kernel"])
+@pytest.mark.parametrize("fx", FX["cluster"], ids=lambda f: f["name"])
+def test_cluster_fixture_through_the_hip_path(oracle, fx, lean):
+    """tests/cluster_test.rs:6-75 through isingmc_import_ops + isingmc_cluster_update, against the oracle: cluster counts, the
+    flipped strings and states, for many seeds (the reference runs it with thread_rng and only expects no panic)."""
+    import isingmontecarlo_amd as im
+    nv = max(2, fx["nvars"])  # (a model needs an edge for its variable count here; the extra variable carries no op)
+    edges = [((0, 1), 1.0)]
+    R, seed = 16, 424242
+    words = cluster_fixture_words(fx, len(edges))
+    state = list(fx["state"]) + [0] * (nv - fx["nvars"])
+    g = im.QmcIsingGraph(edges, 1.0, 0.0, len(words), seed, state=state, nreplicas=R, capacity=64, nvars=nv,
+                         cfg_flags=0 if lean else im.CFG_NO_LEAN_CLUSTER)
+    m = oracle.Model(nv, [[0, 1]], [1.0], 1.0, 0.0)
+    reps = [oracle.Replica(m, 64, len(words), seed, r, state) for r in range(R)]
+    for r in range(R):
+        g.import_ops(words, r)
+        reps[r].set_ops(words)
+    assert g.verify().all()
+    flipped = 0
+    for call in range(6):
+        nc = g.single_cluster_step(flip_free=False)
+        for r, rep in enumerate(reps):
+            assert rep.cluster_update(0.5) == fx["expect_clusters"] == nc[r], (fx["name"], call, r)
+        st = g.state_ref()
+        for r, rep in enumerate(reps):
+            assert np.array_equal(st[r], rep.state()) and np.array_equal(g.export_ops(r), rep.ops())
+            flipped += int(not np.array_equal(g.export_ops(r)[:len(words)], words))
+        assert g.verify().all()
+    assert flipped > 0  # the coins do flip segments

@@ -40,7 +40,7 @@ cap = 1 << int(np.ceil(np.log2(2.0 * a.beta_max * 5.2 * N + 4 * N)))
 g = im.QmcIsingGraph(lat.two_d_ferro(L), 1.0, 0.0, N, a.seed, nreplicas=R, capacity=cap, replica_offset=rank * R, device=local)
 tc = NativeTemperingContainer(g, betas, a.nchains, a.seed, flags=0)
 if a.rccl and world > 1:
-    tc.attach_rccl()
+    tc.attach_rccl()  # (never executed on hardware so far: run tools/rccl_selfcheck.py first on a multi-GPU node)
 for _ in range(a.equilibrate):
     tc.timesteps(1); tc.tempering_step()
 g.reset_accumulators()
