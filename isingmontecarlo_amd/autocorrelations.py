@@ -7,7 +7,9 @@ import numpy as np
 
 
 def fft_autocorrelation_device(samples, device="cuda"):
-    """The same as fft_autocorrelation for a whole batch at once on the GPU (hipFFT): `samples` is [T][R][n], returns [R][T]."""
+    """The same as fft_autocorrelation for a whole batch at once on the GPU (hipFFT): `samples` is [T][R][n], returns [R][T].
+    (A process that uses torch's HIP runtime next to this library must let torch touch the GPU first — `torch.cuda.is_available()`
+    before the first batch is created, as bench.py does; the other order leaves torch without devices.)"""
     import torch
     x = torch.as_tensor(np.ascontiguousarray(samples), dtype=torch.float64, device=device)
     tmax, _, n = x.shape
