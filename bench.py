@@ -59,21 +59,32 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(l, beta, flags, seed, budget_s=20.0):
+def cpu_baseline(l, beta, flags, seed, budget_s=20.0, pmj3d=0, couplings=None):
     """Time the CPU oracle (a C restatement of the reference path, kind='port') on this box's host cores."""
     import _oracle
     import _lattices as lat
     _oracle.build()
-    edges = lattice_edges(l)
-    e, j = lat.split(edges)
     nthreads = max(1, min(_oracle.lib().ora_max_threads(), usable_cores()))
-    m = _oracle.Model(l * l, e, j, 1.0, 0.0)
-    reps = [_oracle.Replica(m, 1 << 18, l * l, seed, 1_000_000 + r) for r in range(nthreads)]
+    eq = 60
+    if pmj3d:  # configs[4] geometry: one +-J realisation per thread (the first rows of the GPU run's couplings)
+        edges = lat.cubic_periodic(pmj3d)
+        e, _ = lat.split(edges)
+        nsite, eq = pmj3d ** 3, 30
+        cap = 1 << int(np_ceil_log2(2.0 * beta * (len(edges) * 1.3 + nsite * 1.2) + 4 * nsite))
+        models = [_oracle.Model(nsite, e, list(couplings[r % len(couplings)]), 1.0, 0.1) for r in range(nthreads)]
+        reps = [_oracle.Replica(models[r], cap, nsite, seed, 1_000_000 + r) for r in range(nthreads)]
+        what = f"{pmj3d}^3 +-J h=0.1"
+    else:
+        edges = lattice_edges(l)
+        e, j = lat.split(edges)
+        m = _oracle.Model(l * l, e, j, 1.0, 0.0)
+        reps = [_oracle.Replica(m, 1 << 18, l * l, seed, 1_000_000 + r) for r in range(nthreads)]
+        what = f"{l}x{l}"
     betas = [beta] * nthreads
     t0 = time.time()
-    _oracle.batch_timesteps(reps, 60, betas, 1, flags, nthreads)  # equilibrate (untimed)
+    _oracle.batch_timesteps(reps, eq, betas, 1, flags, nthreads)  # equilibrate (untimed)
     t_eq = time.time() - t0
-    per_sweep = max(t_eq / 60.0, 1e-4)
+    per_sweep = max(t_eq / eq, 1e-4)
     sweeps = int(max(4, min(200, (budget_s - t_eq) / per_sweep))) if budget_s > t_eq else 4
     for r in reps:
         r.reset_accumulators()
@@ -82,9 +93,14 @@ def cpu_baseline(l, beta, flags, seed, budget_s=20.0):
     dt = time.time() - t0
     upd = sum(int(r.accumulators()[4]) + int(r.accumulators()[5]) for r in reps)
     return {"value": upd / dt, "unit": "spin-op updates/s", "cores": nthreads, "kind": "port",
-            "sample": f"{nthreads} replicas (one per thread) x {sweeps} sweeps of the same {l}x{l} beta={beta} "
-                      f"workload after 60 equilibration sweeps; C oracle, not the Rust binary",
+            "sample": f"{nthreads} replicas (one per thread) x {sweeps} sweeps of the same {what} beta={beta} "
+                      f"workload after {eq} equilibration sweeps; C oracle, not the Rust binary",
             "sweeps_per_s_per_core": sweeps / dt, "host_logical_cpus": os.cpu_count()}
+
+
+def np_ceil_log2(x):
+    import math
+    return math.ceil(math.log2(x))
 
 
 METRIC = "spin-op updates/sec (whole node), 32\u00d732 TFIM, 1024 replicas at 1/2/4/8 GPUs"  # BASELINE.json, verbatim
@@ -169,6 +185,7 @@ def main():
         nsite = L ** 3
         rngJ = np.random.default_rng(args.seed + 7919 * rank)
         couplings = rngJ.choice([-1.0, 1.0], size=(R, len(edges)))
+        couplings_cpu = couplings[:64].copy()
         n_est = beta * (len(edges) * 1.3 + nsite * 1.2)
         cap = 1 << int(np.ceil(np.log2(2.0 * n_est + 4 * nsite)))
         flags &= ~im.FLAG_LOOP
@@ -188,6 +205,7 @@ def main():
     dt = timed_run(g, args.steps, args.warmup, beta, flags, dist, torch)
 
     pass_ms = g.last_pass_ms()
+    g_rvb_ms = g.last_rvb_ms()
     acc = g.accumulators().astype(np.float64)
     updates = float(acc[:, 4].sum() + acc[:, 5].sum())
     slots = float(acc[:, 5].sum())  # sum over replicas and steps of the cutoff M
@@ -227,14 +245,21 @@ def main():
         # per kernel: algorithmic bytes per launch / average launch duration (HIP events recorded around every
         # launch on the launch stream by the library, isingmc_last_pass_ms)
         (ms_diag, ms_rest), (l_diag, l_rest) = pass_ms
-        b_rest = BYTES_PER_SLOT_CLUSTER
-        if args.rvb:
-            b_rest += 8.0  # find_constants reads the op-string twice (count + fill); window traffic not counted
+        ms_rvb, l_rvb = g_rvb_ms
+        ms_rest -= ms_rvb; l_rest -= l_rvb  # the RVB sweep is a kernel of its own: reported on its own line
         kernels = []
-        diag_name = ("sse::sweep_fast_kernel<K,0,LABEL> (diagonal pass + directed loop)" if launch_info.get("fast_diagonal") and not (flags & im.FLAG_HEATBATH)
-                     else "sse::sweep_kernel<W,K,CL,0,PASSES=1> (diagonal pass + directed loop)")
+        diag_name = ("sse::sweep_fast_kernel<K,0,false,false> (diagonal pass + directed loop)" if launch_info.get("fast_diagonal") and not (flags & im.FLAG_HEATBATH)
+                     else "sse::sweep_kernel<W,K,MODE,0,PASSES=1> (diagonal pass + directed loop)")
+        # the cluster launch of the headline geometry is sse::cluster_kernel followed by the general kernel for the replicas it
+        # flagged (its workgroups leave at once otherwise: a few microseconds); both are inside the timed interval
+        if launch_info.get("lean_cluster"):  # (the library counts the pair as one launch of this pass)
+            rest_name = "sse::cluster_kernel<K,HAS_LONG,0> (cluster + free spins + sampling; + sse::sweep_kernel<4,K,1,0,2> for flagged replicas)"
+        else:
+            rest_name = "sse::sweep_kernel<W,K,MODE,0,PASSES=2> (cluster + free spins + sampling)"
         for name, bps, ms, nl in ((diag_name, BYTES_PER_SLOT_DIAG, ms_diag, l_diag),
-                                  ("sse::sweep_kernel<W,K,CL,0,PASSES=%s> (%scluster + free spins)" % (("3 then 2", "RVB sweep, then ") if args.rvb else ("2", "")), b_rest, ms_rest, l_rest)):
+                                  # RVB sweep: find_constants reads the op-string twice (count + fill); window traffic not counted
+                                  ("sse::sweep_kernel<16,K,MODE,0,PASSES=3> (RVB sweep)", 8.0, ms_rvb, l_rvb),
+                                  (rest_name, BYTES_PER_SLOT_CLUSTER, ms_rest, l_rest)):
             if nl == 0:
                 continue
             per_launch_bytes = bps * slots / args.steps
@@ -248,8 +273,8 @@ def main():
             # HBM bytes per launch of the dominant kernel from the PMC passes of this same workload (cannot be
             # collected inside this process: rocprofv3 counters need their own runs), see profiles/README.md
             try:
-                with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
-                    traffic = float(json.load(f)["offdiagonal" if "PASSES=2" in dom["kernel"] else "diagonal"])
+                with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
+                    traffic = float(json.load(f)["offdiagonal" if "cluster" in dom["kernel"].split("(")[0] or "PASSES=2" in dom["kernel"] else "diagonal"])
             except (OSError, KeyError, ValueError):
                 traffic = None
         achieved = dom["achieved_GBps"]
@@ -269,7 +294,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 op words, f64 acceptance arithmetic",
             "data": "synthetic (op-strings equilibrated on device from random spins, Philox seed %d)" % args.seed,
-            "config": {"workload": (f"configs[4] geometry at reduced size: {L}^3 periodic cubic +-J (one disorder realisation per replica) Gamma=1 h=0.1 beta={beta}, "
+            "config": {"workload": (f"configs[4]{'' if L == 32 else ' geometry at reduced size'}: {L}^3 periodic cubic +-J (one disorder realisation per replica) Gamma=1 h=0.1 beta={beta}, "
                                     f"{R} replicas/GPU, QmcIsingGraph::timestep = diagonal + cluster + free spins") if args.pmj3d else
                                    (f"configs[{2 if args.rvb else 1}]: {L}x{L} periodic TFIM J=-1 Gamma=1 h=0 beta={beta}, {R} replicas/GPU, "
                                     f"{'QmcIsingGraph::timestep = diagonal + RVB sweep + ' if args.rvb else 'Qmc::timestep = diagonal + ' + ('directed loop + ' if not args.no_loop else '')}cluster + free spins"),
@@ -294,8 +319,9 @@ def main():
         }
         if strong is not None:
             out["strong_scaling"] = strong
-        if world == 1 and not args.no_cpu_baseline and not args.pmj3d:
-            out["cpu_baseline"] = cpu_baseline(L, beta, flags, args.seed, budget_s=25.0 if args.rvb else 20.0)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L, beta, flags, args.seed, budget_s=25.0 if (args.rvb or args.pmj3d) else 20.0,
+                                               pmj3d=args.pmj3d, couplings=couplings_cpu if args.pmj3d else None)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

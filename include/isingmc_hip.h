@@ -46,7 +46,7 @@ extern "C" {
 /* isingmc_config.flags */
 #define ISINGMC_CFG_NO_LDS_TABLES 1u /* keep the bond table in HBM even when it would fit in LDS (testing) */
 #define ISINGMC_CFG_PER_REPLICA_J 4u /* `J` holds nreplicas x nedges couplings (row r = replica r): independent disorder
-                                        realisations on one graph.  RVB updates are not available in this mode. */
+                                        realisations on one graph. */
 #define ISINGMC_CFG_GLOBAL_TABLES 8u /* keep the per-variable scan tables (spins, cut ranks) in a per-replica HBM scratch instead of
                                         LDS.  Chosen automatically for models whose tables exceed LDS (N >~ 10^4 variables, e.g. a
                                         32^3 lattice); this flag forces the path on any model (testing).  Needs
@@ -268,6 +268,8 @@ int isingmc_synchronize(isingmc_batch *b);
 int isingmc_last_kernel_ms(isingmc_batch *b, float *ms, uint32_t *launches);
 /* the same run split by kernel: ms[0]/launches[0] = diagonal-pass launches, ms[1]/launches[1] = all other launches */
 int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]);
+/* ... and, of ms[1], the part spent in the RVB-sweep launches of split timesteps (0 when none ran) */
+int isingmc_last_rvb_ms(isingmc_batch *b, float *ms, uint32_t *launches);
 /* diagnostic builds (-DSSE_PHASE_TIMING) only: per-replica phase durations in 10-ns ticks, out[R][16]; zero otherwise */
 int isingmc_debug_phase_ticks(isingmc_batch *b, uint64_t *out, int reset);
 /* number of sweeps fused into one kernel launch by isingmc_timesteps (0 = all t steps in one launch) */
@@ -280,6 +282,11 @@ int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
  * most recent off-diagonal launch,
  * out[7]=dynamic LDS bytes of the diagonal-pass launch */
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]);
+/* Host-only: the chunk grid and op-string row stride isingmc_create derives for `capacity` slots and kernels of W (diagonal
+ * launches) / up to Wmax (off-diagonal launches) wave64s per replica at K slots per lane: out = {chunk size, chunks, row stride in
+ * words, tile = slots of the widest whole-tile access}.  Exposed so that the bounds every kernel relies on (whole-tile loads and
+ * stores, the prefetch of an empty chunk range, cached-id rows) can be asserted on a CPU box. */
+int isingmc_plan_geometry(uint32_t capacity, uint32_t W, uint32_t K, uint32_t Wmax, uint32_t out[4]);
 
 #ifdef __cplusplus
 }

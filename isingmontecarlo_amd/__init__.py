@@ -126,6 +126,8 @@ SYMBOLS = {
     "isingmc_set_epoch": (C.c_int, [_vp, _P(C.c_uint64)]),
     "isingmc_itime_magnetization": (C.c_int, [_vp, _P(C.c_int64), _P(C.c_uint64), _P(C.c_uint64)]),
     "isingmc_get_launch_info": (C.c_int, [_vp, _P(_u32)]),
+    "isingmc_last_rvb_ms": (C.c_int, [_vp, _P(C.c_float), _P(_u32)]),
+    "isingmc_plan_geometry": (C.c_int, [_u32, _u32, _u32, _u32, _P(_u32)]),
 }
 
 _LIB = None
@@ -551,6 +553,12 @@ class QmcIsingGraph:
         ms, n = (C.c_float * 2)(), (C.c_uint32 * 2)()
         self._check(self._lib.isingmc_last_pass_ms(self._h, ms, n))
         return (ms[0], ms[1]), (n[0], n[1])
+
+    def last_rvb_ms(self):
+        """(ms, launches) of the RVB-sweep launches of the last run (part of last_pass_ms()[0][1])."""
+        ms, n = C.c_float(), C.c_uint32()
+        self._check(self._lib.isingmc_last_rvb_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def launch_info(self):
         out = (C.c_uint32 * 8)()

@@ -39,8 +39,8 @@ struct isingmc_batch {
     bool lean_cluster = false;          // cluster (+ free spins + sampling) launches use sse_cluster.hip.h when their ids fit its LDS union-find
     bool last_lean = false;             // ... and the last such launch did
     std::vector<hipEvent_t> evpool;     // per-launch events of the split path (bounded, see run())
-    float pass_ms[2] = {0.f, 0.f};      // [0] diagonal-only launches, [1] all other launches of the last run
-    uint32_t pass_launches[2] = {0, 0};
+    float pass_ms[3] = {0.f, 0.f, 0.f}; // [0] diagonal-only launches, [1] all other launches of the last run, [2] of those: the RVB-sweep launches
+    uint32_t pass_launches[3] = {0, 0, 0};
     double offset = 0.0;
     std::vector<double> offsets;        // per-replica energy offsets (ISINGMC_CFG_PER_REPLICA_J), else empty
     bool per_replica_J = false;
@@ -329,7 +329,6 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     if ((domask & SSE_DO_RVB) && b->generic) { b->err = "RVB updates are Ising-specific: not available with generic interactions"; return ISINGMC_ENOTIMPL; }
     if ((domask & SSE_DO_CLUSTER) && b->generic && !b->generic_sym) { b->err = "Cannot perform cluster updates on graphs that break ising symmetry."; return ISINGMC_ENOTIMPL; } // qmc_runner.rs:224-226
     if ((domask & SSE_DO_RVB) && is_tg(b)) { b->err = "RVB updates keep their working set in LDS: not available for models whose per-variable tables live in HBM"; return ISINGMC_ENOTIMPL; }
-    if ((domask & SSE_DO_RVB) && b->per_replica_J) { b->err = "RVB updates with per-replica couplings are not implemented"; return ISINGMC_ENOTIMPL; }
     A.sampling_freq = freq;
     A.domask = domask & 0xFFFFu;
     A.prob = prob;
@@ -358,8 +357,8 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     auto launch = [&](const LaunchCfg &c, const SweepArgs &a) -> hipError_t { return launch_dev(c, b->dev, a); };
     auto fail_launch = [&](hipError_t e) { b->err = std::string("sweep launch: ") + hipGetErrorString(e); return ISINGMC_ENODEVICE; };
     uint32_t launches = 0;
-    b->pass_ms[0] = b->pass_ms[1] = 0.f;
-    b->pass_launches[0] = b->pass_launches[1] = 0;
+    b->pass_ms[0] = b->pass_ms[1] = b->pass_ms[2] = 0.f;
+    b->pass_launches[0] = b->pass_launches[1] = b->pass_launches[2] = 0;
     // passes of the first ("diagonal") launch of a split timestep: the diagonal pass and, unless an RVB sweep has to
     // come in between, the directed loop (one sequential walk: it gains nothing from the wider off-diagonal geometry)
     const uint32_t diag_bits = SSE_DO_DIAG | SSE_DO_HEATBATH | SSE_DO_GROW | ((A.domask & SSE_DO_RVB) ? 0u : SSE_DO_LOOP);
@@ -473,7 +472,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         ld.lds_bytes = use_fast ? (use_label ? b->lds_bytes_fast_label : b->lds_bytes_fast) : diag_lds_bytes(b);
         const uint32_t rest = A.domask & ~diag_bits;
         constexpr size_t MAX_TIMED = 256;
-        const size_t want_ev = 3 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
+        const size_t want_ev = 4 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
         while (b->evpool.size() < want_ev) { hipEvent_t ev; HIP_TRY(b, hipEventCreate(&ev)); b->evpool.push_back(ev); }
         constexpr uint64_t REPLAN_EVERY = 16;
         for (uint64_t done = 0; done < nsteps; ++done) {
@@ -486,11 +485,11 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             const bool timed = done < MAX_TIMED;
             SweepArgs a1 = A;
             a1.domask = (A.domask & diag_bits) | (use_label ? SSE_DO_LABEL : 0u) | (use_compact ? SSE_DO_COMPACT : 0u); a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
-            if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done], b->stream));
+            if (timed) HIP_TRY(b, hipEventRecord(b->evpool[4 * done], b->stream));
             hipError_t e = use_fast ? launch_sweep_fast(ld, b->dev, a1) : launch(ld, a1);
             if (e != hipSuccess) return fail_launch(e);
             launches++; b->pass_launches[0]++;
-            if (timed) HIP_TRY(b, hipEventRecord(b->evpool[3 * done + 1], b->stream));
+            if (timed) HIP_TRY(b, hipEventRecord(b->evpool[4 * done + 1], b->stream));
             const bool sample = freq && (done + 1) % freq == 0;
             uint32_t rest2 = rest;
             if ((rest & SSE_DO_RVB) && !(rest & SSE_DO_LOOP)) {
@@ -502,9 +501,10 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
                 lr.passes = SSE_PASSES_RVB;
                 e = launch_dev(lr, use_dev_off ? dev_off : b->dev, ar);
                 if (e != hipSuccess) return fail_launch(e);
-                launches++; b->pass_launches[1]++;
+                launches++; b->pass_launches[1]++; b->pass_launches[2]++;
                 rest2 = rest & ~SSE_DO_RVB;
             }
+            if (timed) HIP_TRY(b, hipEventRecord(b->evpool[4 * done + 2], b->stream)); // (= the event above when no RVB sweep ran)
             if (rest2 || sample) {
                 SweepArgs a2 = A;
                 a2.domask = rest2; a2.nsteps = 1; a2.step0 = done;
@@ -523,7 +523,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
                 if (e != hipSuccess) return fail_launch(e);
                 launches++; b->pass_launches[1]++;
             }
-            if (timed) { HIP_TRY(b, hipEventRecord(b->evpool[3 * done + 2], b->stream)); timed_steps++; }
+            if (timed) { HIP_TRY(b, hipEventRecord(b->evpool[4 * done + 3], b->stream)); timed_steps++; }
         }
     }
     HIP_TRY(b, hipEventRecord(b->ev1, b->stream));
@@ -533,12 +533,13 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     if (!split) b->pass_ms[1] = b->last_ms;
     for (size_t i = 0; i < timed_steps; ++i) {
         float t = 0.f;
-        if (hipEventElapsedTime(&t, b->evpool[3 * i], b->evpool[3 * i + 1]) == hipSuccess) b->pass_ms[0] += t;
-        if (hipEventElapsedTime(&t, b->evpool[3 * i + 1], b->evpool[3 * i + 2]) == hipSuccess) b->pass_ms[1] += t;
+        if (hipEventElapsedTime(&t, b->evpool[4 * i], b->evpool[4 * i + 1]) == hipSuccess) b->pass_ms[0] += t;
+        if (hipEventElapsedTime(&t, b->evpool[4 * i + 1], b->evpool[4 * i + 3]) == hipSuccess) b->pass_ms[1] += t;
+        if (hipEventElapsedTime(&t, b->evpool[4 * i + 1], b->evpool[4 * i + 2]) == hipSuccess) b->pass_ms[2] += t;
     }
     if (split && timed_steps && timed_steps < nsteps) { // scale the sampled steps up to the whole run
         const float f = (float)nsteps / (float)timed_steps;
-        b->pass_ms[0] *= f; b->pass_ms[1] *= f;
+        b->pass_ms[0] *= f; b->pass_ms[1] *= f; b->pass_ms[2] *= f;
     }
     if (rc) return rc;
     if (out_host) HIP_TRY(b, hipMemcpy(out_host, b->d_out, sizeof(uint32_t) * b->dev.R, hipMemcpyDeviceToHost));
@@ -565,6 +566,25 @@ int isingmc_interaction_sym_under_ising(const isingmc_interaction *it, int *out)
     for (uint32_t i = 0; i < upto; ++i)
         if (!(std::fabs(it->mat[i] - it->mat[(~i) & mask]) < DBL_EPSILON)) sym = 0;
     *out = sym;
+    return ISINGMC_OK;
+}
+
+// Chunk grid of the per-chunk counters and the row stride of the op-string (and of every per-slot scratch row) for a batch whose
+// kernels run with W waves (diagonal launches) and up to Wmax waves (off-diagonal launches) of K slots per lane.
+//   CH      chunk size: <= SSE_MAX_CHUNKS chunks cover the capacity, CH a multiple of 256 (= a wave's tile at K = 4, two at K = 2)
+//   stride  whole tiles of EITHER geometry (full-tile loads and stores never leave the row) and at least the chunk-rounded
+//           capacity + 256: a cluster-scan wave whose chunk range is empty still prefetches one wave-tile at its range start
+int isingmc_plan_geometry(uint32_t capacity, uint32_t W, uint32_t K, uint32_t Wmax, uint32_t out[4]) {
+    if (!out || capacity == 0 || W == 0 || K == 0 || Wmax < W) return ISINGMC_EINVAL;
+    const size_t CH = (((size_t)capacity + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256;
+    const size_t nchunks = ((size_t)capacity + CH - 1) / CH;
+    const size_t tile = (Wmax % W == 0 ? (size_t)Wmax : (size_t)Wmax * W) * 64 * K; // whole tiles of either launch geometry
+    const size_t need1 = ((size_t)capacity + tile - 1) / tile * tile;
+    const size_t need2 = ((size_t)capacity + CH - 1) / CH * CH + 256;
+    const size_t need = need1 > need2 ? need1 : need2;
+    const size_t stride = (need + tile - 1) / tile * tile;
+    if (stride > 0xFFFFFFFFull / 4) return ISINGMC_EINVAL; // byte offsets inside a row are 32-bit (row_ld / row_st)
+    out[0] = (uint32_t)CH; out[1] = (uint32_t)nchunks; out[2] = (uint32_t)stride; out[3] = (uint32_t)tile;
     return ISINGMC_OK;
 }
 
@@ -745,16 +765,11 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     b->w8_ok = w8_possible && !W_off;
     const uint32_t Wmax = W_off ? (W_off > W ? W_off : W) : ((W < 16 && w16_possible) ? 16u : (w8_possible ? 8u : W));
     const size_t ids_max = (size_t)Wmax * D.N + D.cap;
-    // chunk grid for the per-chunk counters: <= SSE_MAX_CHUNKS chunks of CH slots, CH a multiple of 256
-    D.CH = (uint32_t)((((size_t)D.cap + SSE_MAX_CHUNKS - 1) / SSE_MAX_CHUNKS + 255) / 256 * 256);
-    D.nchunks = (D.cap + D.CH - 1) / D.CH;
     b->W = W; b->K = K; b->mode = TG ? SSE_MODE_GLOBAL_TABLES : (CL ? SSE_MODE_LDS_EDGES : SSE_MODE_GENERAL); b->W_off = W_off;
-    { // row stride: whole tiles, plus room for the (unused) prefetch of a cluster-scan wave whose chunk range is empty
-        const size_t tile = (Wmax % W == 0 ? (size_t)Wmax : (size_t)Wmax * W) * 64 * K; // whole tiles of either launch geometry
-        const size_t need1 = ((size_t)D.cap + tile - 1) / tile * tile;
-        const size_t need2 = ((size_t)D.cap + D.CH - 1) / D.CH * D.CH + 256;
-        const size_t need = need1 > need2 ? need1 : need2;
-        D.stride = (uint32_t)((need + tile - 1) / tile * tile);
+    { // chunk grid and row stride: one function (also exported for the CPU-side bound checks of tests/test_abi_cpu.py)
+        uint32_t geo[4];
+        if (isingmc_plan_geometry(D.cap, W, K, Wmax, geo) != ISINGMC_OK) { b->err = "capacity too large for the row stride"; return fail(ISINGMC_EINVAL); }
+        D.CH = geo[0]; D.nchunks = geo[1]; D.stride = geo[2];
     }
     b->lds_fixed_words_ = fixed; b->lds_total_words = total_words; b->uf_ids_limit = cfg->lds_uf_ids_limit;
     b->lds_bytes_fast = fast_lds_bytes(D.N, D.nwords, D.E, D.Nb, false);
@@ -1235,6 +1250,12 @@ int isingmc_last_pass_ms(isingmc_batch *b, float ms[2], uint32_t launches[2]) {
     if (!b) return ISINGMC_EINVAL;
     if (ms) { ms[0] = b->pass_ms[0]; ms[1] = b->pass_ms[1]; }
     if (launches) { launches[0] = b->pass_launches[0]; launches[1] = b->pass_launches[1]; }
+    return ISINGMC_OK;
+}
+int isingmc_last_rvb_ms(isingmc_batch *b, float *ms, uint32_t *launches) {
+    if (!b) return ISINGMC_EINVAL;
+    if (ms) *ms = b->pass_ms[2];
+    if (launches) *launches = b->pass_launches[2];
     return ISINGMC_OK;
 }
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {

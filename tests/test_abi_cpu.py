@@ -224,3 +224,44 @@ def test_serde_dict_follows_the_reference_struct_definitions():
     assert m["var_ends"] == [[{"p": 0, "relv": 0}, {"p": 0, "relv": 0}], [{"p": 0, "relv": 1}, {"p": 2, "relv": 0}], [{"p": 3, "relv": 0}, {"p": 3, "relv": 0}]]
     assert m["alloc"]["usize_alloc"] == {"instances": 10, "gen_more": False} and m["alloc"]["binary_heap_alloc"]["instances"] == 1
     assert d["run_rvb_steps"] and d["classical_bonds"] == [[0], [0, 1], [1]] and d["total_rvb_successes"] == 5 and d["rvb_clusters_counted"] == 9
+
+
+def test_row_stride_covers_every_whole_tile_access():
+    """Bounds audit of the op-string rows (isingmc_plan_geometry, the function isingmc_create itself uses): for every launch geometry
+    a batch can run with, the largest slot index any kernel forms stays inside the row.
+      * diagonal / cached-apply passes stream whole tiles of W * 64 * K slots up to the cutoff (<= capacity);
+      * a cluster-scan wave owns ceil(used / W) chunks and loads / stores wave-tiles of 64 * K slots from its range start — also
+        when its range is empty (range start = end of the chunk-rounded string): that prefetch needs the + 256;
+      * the dedicated cluster kernel keeps one 16-bit id per slot, two rows per dword, in the first half of a scratch row.
+    (Round 2 saw a GPU memory fault in an uncommitted experiment on the 16-wave HBM-table path; the shipped index arithmetic
+    is checked here for all geometries instead of trusting one passing run.)"""
+    import isingmontecarlo_amd as im
+    lib = im.load_library()
+    out = (C.c_uint32 * 4)()
+    rng = np.random.default_rng(5)
+    caps = [1, 2, 63, 64, 255, 256, 257, 1023, 1024, 4095, 4096, 4097, 8192, 32768 + 1, 1 << 18, (1 << 18) + 777, 1 << 20, 3_000_001] + [int(x) for x in rng.integers(1, 1 << 22, 60)]
+    for cap in caps:
+        for W, Wmax in [(1, 1), (4, 4), (4, 8), (4, 16), (6, 6), (6, 16), (8, 8), (8, 16), (16, 16), (1, 16)]:
+            for K in (1, 2, 4):
+                assert lib.isingmc_plan_geometry(cap, W, K, Wmax, out) == 0
+                CH, nchunks, stride, tile = (int(x) for x in out)
+                assert CH % 256 == 0 and nchunks <= 128 and CH * nchunks >= cap
+                for Wk in {W, Wmax, 8 if Wmax >= 8 and W < 8 else W}:  # (8 waves: the HBM union-find geometry of run())
+                    if Wmax % Wk and Wk != W:
+                        continue
+                    ts = Wk * 64 * K
+                    assert stride % ts == 0, (cap, W, Wmax, K, Wk)
+                    # whole-tile streaming up to any cutoff M <= cap: last slot touched = roundup(M, ts) - 1
+                    assert (cap + ts - 1) // ts * ts <= stride
+                    # cluster scan: wave ranges in chunks, wave-tiles of 64 K slots from the range start, prefetch even when empty
+                    for M in {cap, max(1, cap // 2), max(1, cap - 1)}:
+                        used = (M + CH - 1) // CH
+                        q = (used + Wk - 1) // Wk
+                        for w in range(Wk):
+                            c0 = min(w * q, used); c1 = min(c0 + q, used)
+                            pbeg, pend = c0 * CH, min(c1 * CH, M)
+                            last = pbeg + 64 * K - 1  # the unconditional prefetch at the range start
+                            if pend > pbeg:
+                                last = max(last, pbeg + ((pend - pbeg + 64 * K - 1) // (64 * K)) * 64 * K - 1)
+                            assert last < stride, (cap, W, Wmax, K, Wk, M, w, last, stride)
+                            assert (last >> 1) + 64 < stride  # 16-bit ids of the dedicated cluster kernel (K >= 2): dword (p0 >> 1) + 32 j + lane

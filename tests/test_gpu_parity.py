@@ -332,8 +332,17 @@ def test_disorder_realisations_cubic_pm_j(oracle, waves, heatbath):
     # different realisations, different offsets only through sum |J| (equal here): energies differ through n
     assert np.allclose(g.get_offsets(), g.get_offset())
     assert len(set(int(x) for x in g.get_n())) > 1
-    with pytest.raises(im.IsingMcError):
-        g.single_rvb_sweep()
+    # RVB sweeps on per-replica couplings (qmc_ising.rs:705-752: with h != 0 every cluster that holds a longitudinal op is
+    # frozen, and the reference relies on RVB moves for exactly this +-J + field workload): standalone sweeps and whole timesteps
+    for it in range(3):
+        succ, upd = g.single_rvb_sweep()
+        for r, rep in enumerate(reps):
+            assert succ[r] == rep.rvb_update(upd), (it, r)
+        assert_same(g, reps, f"cubic +-J rvb sweep {it}")
+    g.run(12, beta, flags=flags | im.FLAG_RVB)
+    oracle.batch_timesteps(reps, 12, [beta] * R, 1, flags | im.FLAG_RVB)
+    assert_same(g, reps, "cubic +-J timesteps with RVB")
+    assert g.verify().all()
 
 
 def test_itime_magnetization_fold(oracle):

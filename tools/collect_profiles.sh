@@ -4,7 +4,7 @@
 # profiles/README.md describes are then copied by tools/collect_profiles.py.
 set -e -o pipefail
 export TMPDIR=/tmp
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 O=gpurun_out/profiles_raw
 mkdir -p $O
 python bench.py > $O/${R}_bench.json
@@ -13,7 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 2 > /dev/null
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq1 -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > /dev/null
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > /dev/null
-python bench.py --pmj3d 32 --beta 4 --replicas 512 --equilibrate 60 --steps 10 --warmup 2 --no-cpu-baseline > $O/${R}_bench_pmj3d32.json
+python bench.py --pmj3d 32 --beta 4 --replicas 512 --equilibrate 60 --steps 10 --warmup 2 > $O/${R}_bench_pmj3d32.json
 python bench.py --pmj3d 16 --beta 4 --replicas 512 --equilibrate 60 --steps 20 --warmup 3 --no-cpu-baseline > $O/${R}_bench_pmj3d16.json
 python bench.py --rvb --steps 4 --warmup 1 --equilibrate 60 > $O/${R}_bench_config2_rvb.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_rvb -- python3 bench.py --rvb --steps 4 --warmup 1 --equilibrate 60 --no-cpu-baseline > /dev/null

@@ -87,8 +87,6 @@ def main():
     print(f"# {'kernel':<78} {'VGPR':>5} {'AGPR':>5} {'SGPR':>5} {'vspill':>6} {'sspill':>6} {'scratch_B':>9} {'static_LDS_B':>12} {'threads':>7}")
     for r in rows:
         p = r["pretty"]
-        if not show_all and re.search(r"sweep\w*_kernel<.*, 1, ", p + " ") and ", 1, " in p.split("<", 1)[1][6:]:
-            pass
         if not show_all and is_prep_symbol(p):
             continue
         print(f"  {p:<78} {r.get('vgpr_count', '?'):>5} {r['agpr']:>5} {r.get('sgpr_count', '?'):>5} {r.get('vgpr_spill_count', '?'):>6} "
@@ -104,7 +102,9 @@ def is_prep_symbol(pretty):
     m = re.match(r"sse::sweep_fast_kernel<(\d+), (\d+),", pretty)
     if m:
         return m.group(2) == "1"
-    m = re.match(r"sse::\w+_kernel<.*?PH(\d)", pretty)
+    m = re.match(r"sse::cluster_kernel<(\d+), (\w+), (\d+)>", pretty)
+    if m:
+        return m.group(3) == "1"
     return False
 
 
