@@ -86,16 +86,21 @@ __device__ __forceinline__ uint32_t cl_entry(const DevBatch &B, uint32_t b, uint
     return v | (v << 13) | SSE_CLE_LONG;
 }
 
-// union on trees that only the calling wave touches (see uf_union_wave); returns the surviving root
+// union on trees that only the calling wave touches (see uf_union_wave); returns the surviving root.  Both walks to the roots
+// advance together (two independent LDS reads per step instead of two walks one after the other), and the two start nodes are
+// re-pointed at their roots (they are not roots themselves when they differ from them)
 __device__ __forceinline__ uint32_t cl_union_wave(const UFA<false> &uf, uint32_t a, uint32_t b) {
     for (;;) {
-        a = uf_find(uf, a);
-        b = uf_find(uf, b);
-        if (a == b) return a;
-        if (a > b) { const uint32_t t = a; a = b; b = t; }
-        uf.set(b, a);
+        uint32_t xa = a, xb = b, pa = uf.get(a), pb = uf.get(b);
+        while ((pa != xa) | (pb != xb)) { xa = pa; xb = pb; pa = uf.get(xa); pb = uf.get(xb); } // (a root is its own parent: it stays put)
+        if (a != xa) uf.set(a, xa);
+        if (b != xb) uf.set(b, xb);
+        if (xa == xb) return xa;
+        const uint32_t lo = min(xa, xb), hi = max(xa, xb);
+        uf.set(hi, lo);
         SSE_WAVE_FENCE();
-        if (uf.get(b) == a) return a;
+        if (uf.get(hi) == lo) return lo;
+        a = xa; b = xb;
     }
 }
 
@@ -250,17 +255,23 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                 const bool need = ua[j] != uc[j];
                 if (!sse_any(need) || SSE_DBG(B, 2u)) continue; // wave-uniform
                 if (need) {
+                    // three levels up from each representative, straight-line (a representative is a root or close to one: it was
+                    // a root when it was written); nodes found below a root are re-pointed at it on the way (they are not roots, so
+                    // no link of this batch can be undone by that)
                     const uint32_t pa = LDS16B(par_b + 2u * ua[j]), pc = LDS16B(par_b + 2u * uc[j]);
                     const uint32_t ga = LDS16B(par_b + 2u * pa), gc = LDS16B(par_b + 2u * pc);
-                    const bool differ = pa != pc;
-                    const bool roots = (ga == pa) & (gc == pc);
-                    const bool link = differ & roots;
-                    uint32_t lo = min(pa, pc);
-                    const uint32_t hi = max(pa, pc);
+                    const uint32_t ta = LDS16B(par_b + 2u * ga), tc = LDS16B(par_b + 2u * gc);
+                    const bool found = (ta == ga) & (tc == gc); // ga / gc are roots (also when the chain is shorter: a root is its own parent)
+                    const bool differ = ga != gc;
+                    const bool link = found & differ;
+                    uint32_t lo = min(ga, gc);
+                    const uint32_t hi = max(ga, gc);
+                    if (found & (pa != ga)) { LDS16B(par_b + 2u * ua[j]) = (uint16_t)ga; }
+                    if (found & (pc != gc)) { LDS16B(par_b + 2u * uc[j]) = (uint16_t)gc; }
                     if (link) LDS16B(par_b + 2u * hi) = (uint16_t)lo;
                     SSE_WAVE_FENCE();
                     const uint32_t chk = LDS16B(par_b + 2u * hi);
-                    if ((differ & !roots) | (link & (chk != lo))) lo = cl_union_wave(uf, pa, pc);
+                    if ((!found | (link & (chk != lo))) && !SSE_DBG(B, 16u)) lo = cl_union_wave(uf, pa, pc);
                     // both legs' entries now name the surviving root (or the common parent found one hop up)
                     lds_cas32(adra[j], ua[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
                     lds_cas32(adrc[j], uc[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
