@@ -63,6 +63,8 @@ extern "C" {
                                             side on the waves of the workgroup (testing: the results are the same either way) */
 #define ISINGMC_CFG_NO_LEAN_CLUSTER 256u /* run cluster updates through the general kernel even where the dedicated one (csrc/sse_cluster.hip.h:
                                            LDS edge tables, N <= 4095, default wave counts) applies (testing / A-B timing) */
+#define ISINGMC_CFG_NO_DEFERRED_FLIPS 512u /* the dedicated cluster kernel rewrites the op-strings itself instead of leaving one flip byte per slot
+                                             for the diagonal launch of the next timestep to apply (testing / A-B timing) */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 

@@ -38,6 +38,8 @@ struct isingmc_batch {
     bool fused_launch = false;          // ISINGMC_CFG_FUSED_LAUNCH: whole timesteps in one kernel (no diagonal-only launches)
     bool lean_cluster = false;          // cluster (+ free spins + sampling) launches use sse_cluster.hip.h when their ids fit its LDS union-find
     bool last_lean = false;             // ... and the last such launch did
+    bool defer = false;                 // ... leaving its flips as one byte per slot for the next (trimmed) diagonal launch to apply
+    bool pending = false;               // some replicas' strings in HBM may still wait for their flip bytes (DevBatch::pend says which)
     std::vector<hipEvent_t> evpool;     // per-launch events of the split path (bounded, see run())
     float pass_ms[3] = {0.f, 0.f, 0.f}; // [0] diagonal-only launches, [1] all other launches of the last run, [2] of those: the RVB-sweep launches
     uint32_t pass_launches[3] = {0, 0, 0};
@@ -207,6 +209,27 @@ __global__ __launch_bounds__(256) void debug_counts_kernel(DevBatch B, uint32_t 
     if (threadIdx.x < 3) out[3 * r + threadIdx.x] = red[threadIdx.x];
 }
 
+// Deferred cluster flips (sse_cluster.hip.h) applied in place: ops[p] ^= flip byte, for the replicas whose flag is set.  Used by
+// every consumer of the op-strings other than the trimmed diagonal kernel, which applies the bytes itself while it streams.
+__global__ __launch_bounds__(1024) void materialize_kernel(DevBatch B) {
+    const uint32_t r = blockIdx.x;
+    if (!B.pend[r]) return; // (uniform per workgroup)
+    uint32_t *ops = B.ops + (size_t)r * B.stride;
+    const uint8_t *fb = B.flipb + (size_t)r * B.stride;
+    const uint32_t M = B.cutoff[r];
+    for (uint32_t p = threadIdx.x; p < M; p += blockDim.x) { const uint32_t f = fb[p]; if (f) ops[p] ^= f; }
+    __syncthreads();
+    if (threadIdx.x == 0) B.pend[r] = 0u;
+}
+static int ensure_materialized(isingmc_batch *b) {
+    if (!b->pending) return ISINGMC_OK;
+    hipLaunchKernelGGL(materialize_kernel, dim3(b->dev.R), dim3(1024), 0, b->stream, b->dev);
+    HIP_TRY(b, hipGetLastError());
+    HIP_TRY(b, hipStreamSynchronize(b->stream)); // (callers read the strings with blocking copies or their own kernels on this stream; keep it simple)
+    b->pending = false;
+    return ISINGMC_OK;
+}
+
 static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, bool tg = false) {
     // mirrors Lds<W>::carve up to and including o_cl: state, touched bits, touched bytes, round buffers, misc, chunk counters,
     // edge table, per-wave rank tables (u16) and marker tables (u8); with the tables in HBM (tg) only the bit arrays remain
@@ -329,6 +352,11 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     if ((domask & SSE_DO_RVB) && b->generic) { b->err = "RVB updates are Ising-specific: not available with generic interactions"; return ISINGMC_ENOTIMPL; }
     if ((domask & SSE_DO_CLUSTER) && b->generic && !b->generic_sym) { b->err = "Cannot perform cluster updates on graphs that break ising symmetry."; return ISINGMC_ENOTIMPL; } // qmc_runner.rs:224-226
     if ((domask & SSE_DO_RVB) && is_tg(b)) { b->err = "RVB updates keep their working set in LDS: not available for models whose per-variable tables live in HBM"; return ISINGMC_ENOTIMPL; }
+    // Pending cluster flips: only a call whose first launch is the trimmed diagonal kernel may start on the un-flipped strings
+    {
+        const bool first_is_fast_diag = !b->fused_launch && (domask & SSE_DO_DIAG) && b->fast_diag && !(domask & SSE_DO_HEATBATH) && b->defer;
+        if (b->pending && !first_is_fast_diag) { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
+    }
     A.sampling_freq = freq;
     A.domask = domask & 0xFFFFu;
     A.prob = prob;
@@ -433,8 +461,11 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         ll.W = 16; ll.K = b->K; ll.lds_bytes = lean.lds_bytes;
         DevBatch dv = b->dev;
         dv.lds_ufcap = lean.ufcap; dv.lds_words = (uint32_t)(lean.lds_bytes / 4);
-        hipError_t e = launch_cluster(ll, dv, a);
+        SweepArgs al = a;
+        al.defer_flips = b->defer ? 1u : 0u;
+        hipError_t e = launch_cluster(ll, dv, al);
         if (e != hipSuccess) return e;
+        if (b->defer) b->pending = true;
         LaunchCfg lf = lc;
         lf.W = b->W; lf.passes = SSE_PASSES_OFFDIAG;
         const LdsPlan pf = plan_lds(b, b->W);
@@ -485,6 +516,10 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             const bool timed = done < MAX_TIMED;
             SweepArgs a1 = A;
             a1.domask = (A.domask & diag_bits) | (use_label ? SSE_DO_LABEL : 0u) | (use_compact ? SSE_DO_COMPACT : 0u); a1.nsteps = 1; a1.step0 = done; a1.sampling_freq = 0; a1.out_u32 = nullptr;
+            if (b->pending) { // (every step of a run after the first: the cluster update of the step before left flip bytes)
+                if (use_fast && b->defer) { a1.defer_flips = 1u; b->pending = false; }
+                else { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
+            }
             if (timed) HIP_TRY(b, hipEventRecord(b->evpool[4 * done], b->stream));
             hipError_t e = use_fast ? launch_sweep_fast(ld, b->dev, a1) : launch(ld, a1);
             if (e != hipSuccess) return fail_launch(e);
@@ -814,6 +849,11 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     }
     if ((rc = dalloc(b, &D.chunks, (size_t)D.R * 2 * SSE_MAX_CHUNKS))) return fail(rc);
     if ((rc = dalloc(b, &D.segs, (size_t)D.R * D.stride, false))) return fail(rc);
+    b->defer = b->lean_cluster && b->fast_diag && !(cfg->flags & ISINGMC_CFG_NO_DEFERRED_FLIPS);
+    if (b->defer) { // flip bytes start (and stay, beyond every cutoff) zero
+        if ((rc = dalloc(b, &D.flipb, (size_t)D.R * D.stride))) return fail(rc);
+        if ((rc = dalloc(b, &D.pend, D.R))) return fail(rc);
+    }
     if ((rc = dalloc(b, &D.dbg, (size_t)D.R * 16))) return fail(rc);
     BondRec *dbonds = nullptr; double *dcum = nullptr;
     if ((rc = dalloc(b, &dbonds, (size_t)nH * D.Nb, false))) return fail(rc);
@@ -1125,12 +1165,14 @@ int isingmc_set_cutoff(isingmc_batch *b, uint32_t r, uint32_t cutoff) {
 int isingmc_export_ops(isingmc_batch *b, uint32_t r, uint32_t *words, uint32_t nwords) {
     if (!b || !words || r >= b->dev.R || nwords > b->dev.cap) { if (b) b->err = "bad arguments to export_ops"; return ISINGMC_EINVAL; }
     HIP_TRY(b, hipSetDevice(b->device));
+    { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
     HIP_TRY(b, hipMemcpy(words, b->dev.ops + (size_t)r * b->dev.stride, sizeof(uint32_t) * nwords, hipMemcpyDeviceToHost));
     return ISINGMC_OK;
 }
 int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint32_t nwords) {
     if (!b || (!words && nwords) || r >= b->dev.R) { if (b) b->err = "bad arguments to import_ops"; return ISINGMC_EINVAL; }
     if (nwords > b->dev.cap) { b->err = "op-string longer than capacity"; return ISINGMC_ECAPACITY; }
+    { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
     uint32_t n = 0, ntr = 0;
     const size_t hoff = b->per_replica_J ? (size_t)(b->ham_row_host.empty() ? r : b->ham_row_host[r]) * b->dev.Nb : 0; // this replica's bond table
     std::vector<uint32_t> chunks(2 * SSE_MAX_CHUNKS, 0u);
@@ -1166,6 +1208,7 @@ int isingmc_import_ops(isingmc_batch *b, uint32_t r, const uint32_t *words, uint
 int isingmc_itime_magnetization(isingmc_batch *b, int64_t *sum_m, uint64_t *sum_m2, uint64_t *sum_abs_m) {
     if (!b || !sum_m || !sum_m2 || !sum_abs_m) { if (b) b->err = "bad arguments to itime_magnetization"; return ISINGMC_EINVAL; }
     HIP_TRY(b, hipSetDevice(b->device));
+    { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
     const uint32_t R = b->dev.R;
     long long *d1 = nullptr; unsigned long long *d2 = nullptr, *d3 = nullptr;
     HIP_TRY(b, hipMalloc(&d1, sizeof(long long) * R));
@@ -1196,6 +1239,7 @@ int isingmc_get_bond_count(isingmc_batch *b, uint32_t r, uint32_t bond, uint32_t
 int isingmc_debug_counts(isingmc_batch *b, uint32_t *out) {
     if (!b || !out) return ISINGMC_EINVAL;
     HIP_TRY(b, hipSetDevice(b->device));
+    { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
     uint32_t *d = nullptr;
     HIP_TRY(b, hipMalloc((void **)&d, 12 * (size_t)b->dev.R));
     hipLaunchKernelGGL(debug_counts_kernel, dim3(b->dev.R), dim3(256), 0, b->stream, b->dev, d);
@@ -1209,6 +1253,7 @@ int isingmc_debug_counts(isingmc_batch *b, uint32_t *out) {
 int isingmc_verify(isingmc_batch *b, uint8_t *ok) {
     if (!b || !ok) return ISINGMC_EINVAL;
     HIP_TRY(b, hipSetDevice(b->device));
+    { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
     hipLaunchKernelGGL(verify_kernel, dim3((b->dev.R + 63) / 64), dim3(64), 0, b->stream, b->dev, b->d_vstate, b->d_ok);
     HIP_TRY(b, hipGetLastError());
     HIP_TRY(b, hipMemcpyAsync(ok, b->d_ok, b->dev.R, hipMemcpyDeviceToHost, b->stream));
@@ -1542,6 +1587,7 @@ int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps) {
     PtState *P = b->pt;
     HIP_TRY(b, hipSetDevice(b->device));
     const uint32_t R = b->dev.R, K = P->nchains, T = P->ntemps, tper = P->tper, E = b->dev.E, Nb = b->dev.Nb;
+    { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
     const uint32_t t_lo = P->rank * tper, t_hi = t_lo + tper; // my temperature block [t_lo, t_hi)
     const int prev = P->rank > 0 ? (int)P->rank - 1 : -1, next = P->rank + 1 < P->world ? (int)P->rank + 1 : -1;
     uint64_t swaps = 0;

@@ -131,6 +131,9 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
     uint64_t epoch = B.epoch[r];
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     uint32_t *ids = B.segs + (size_t)r * B.stride;    // 16-bit ids, rows 2k and 2k+1 share dword (p >> 1 rounded to the pair) + lane
+    // deferred flips (A.defer_flips): the row masks live behind the ids (second half of the scratch row: 16 B per 64 slots)
+    const bool DEFER = A.defer_flips != 0u && B.flipb != nullptr;
+    uint4 *msk = reinterpret_cast<uint4 *>(ids + B.stride / 2u);
 
     SSE_STAMP_INIT;
     // ---- initialisation ----
@@ -171,8 +174,9 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
     {
         uint32_t cutnext = N + cutbase; // id of the next cut of this range
         uint32_t wnext[K], idpend[K / 2];
+        uint4 mpend[K]; // deferred flips: the cut mask and the two-site mask of every row (the same in all lanes; lane 0 stores them)
 #pragma unroll
-        for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, pbeg + (uint32_t)(j * 64 + lane));
+        for (int j = 0; j < K; ++j) { wnext[j] = row_ld(ops, pbeg + (uint32_t)(j * 64 + lane)); mpend[j] = make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
         for (int j = 0; j < K / 2; ++j) idpend[j] = 0u;
         uint32_t pprev = pbeg;
@@ -187,6 +191,10 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                 // whole tile to complete, not for stores issued a moment ago (first tile: a dummy store that the next one overwrites)
 #pragma unroll
                 for (int j = 0; j < K; j += 2) if (!SSE_DBG(B, 1u)) row_st(ids, (pprev >> 1) + (uint32_t)(j * 32 + lane), idpend[j / 2]);
+                if (DEFER) { if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) msk[(pprev >> 6) + (uint32_t)j] = mpend[j];
+                } }
                 pprev = p0;
                 const uint32_t pn0 = p0 + TS < pend ? p0 + TS : p0;
 #pragma unroll
@@ -239,6 +247,10 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                 if constexpr (HAS_LONG)
                     if (e[j] & SSE_CLE_LONG) uf.frozen_or(seg_a >> 5, 1u << (seg_a & 31)); // qmc_ising.rs:759-775
                 cutnext += (uint32_t)popc64(cutm);
+                if (DEFER) { // (without a longitudinal field every op that is not a cut is a two-site op: the cut mask alone will do)
+                    mpend[j].x = (uint32_t)cutm; mpend[j].y = (uint32_t)(cutm >> 32);
+                    if constexpr (HAS_LONG) { const uint64_t twom = sse_ballot((e[j] & SSE_CLE_TWO) != 0u); mpend[j].z = (uint32_t)twom; mpend[j].w = (uint32_t)(twom >> 32); }
+                }
                 ua[j] = seg_a; uc[j] = seg_c; // (one-variable ops and empty slots: seg_c == seg_a, no union below)
             }
             // one 16-bit id per slot for the apply pass: the input leg's representative (a two-site op's other leg is in the same
@@ -281,6 +293,10 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
         if (pbeg < pend) {
 #pragma unroll
             for (int j = 0; j < K; j += 2) row_st(ids, (pprev >> 1) + (uint32_t)(j * 32 + lane), idpend[j / 2]);
+            if (DEFER) { if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) msk[(pprev >> 6) + (uint32_t)j] = mpend[j];
+            } }
         }
     }
     __syncthreads();
@@ -368,6 +384,68 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
     SSE_STAMP(4);
 
     // ---- apply (cluster.rs:139-167): input bits flip with the incoming segment, output bits with the outgoing one ----
+    if (DEFER) {
+        // Deferred: the op-string is not touched.  Every slot gets the xor mask of its four state bits as one byte (0 for an empty
+        // slot); the diagonal pass of the next timestep applies it while it streams the string (sse_fast.hip.h), any other reader
+        // goes through materialize_kernel first.  Reads 2 B of ids + 16 B of row masks per row, writes 1 B per slot: a quarter
+        // of the traffic of the in-place pass below.
+        uint32_t cutnext = N + cutbase;
+        uint8_t *fb = B.flipb + (size_t)r * B.stride;
+        // The loop body is short, so the loads run D tiles ahead (one tile per memory round trip would leave the pass waiting):
+        // per tile two dwords of ids per lane and the 64 bytes of row masks, one dword per lane 0..15 (read back with v_readlane)
+        constexpr int D = 3;
+        const uint32_t *mskw = reinterpret_cast<const uint32_t *>(msk);
+        uint32_t qid[D][K / 2], qmk[D], bpend[K];
+        auto issue = [&](int slot, uint32_t pt) { // loads of the tile at pt (clamped to the last tile of the range: values unused beyond it)
+            const uint32_t pc = pt < pend ? pt : pbeg;
+#pragma unroll
+            for (int j = 0; j < K; j += 2) qid[slot][j / 2] = row_ld(ids, (pc >> 1) + (uint32_t)(j * 32 + lane));
+            qmk[slot] = row_ld(mskw, (pc >> 6) * 4u + (uint32_t)(lane & 15));
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d, pbeg + (uint32_t)d * TS);
+#pragma unroll
+        for (int j = 0; j < K; ++j) bpend[j] = 0u;
+        uint32_t pprev = pbeg;
+        bool first = true;
+        for (uint32_t p0 = pbeg; p0 < pend; p0 += TS) {
+            uint32_t id2[K / 2];
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) id2[j] = qid[0][j];
+            const uint32_t mkv = qmk[0];
+#pragma unroll
+            for (int d = 0; d + 1 < D; ++d) {
+#pragma unroll
+                for (int j = 0; j < K / 2; ++j) qid[d][j] = qid[d + 1][j];
+                qmk[d] = qmk[d + 1];
+            }
+            if (!first) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) fb[pprev + (uint32_t)(j * 64 + lane)] = (uint8_t)bpend[j];
+            }
+            first = false;
+            pprev = p0;
+            issue(D - 1, p0 + (uint32_t)D * TS);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint64_t cutm = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mkv, 4 * j) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mkv, 4 * j + 1) << 32);
+                const uint32_t own = __builtin_amdgcn_mbcnt_hi((uint32_t)(cutm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cutm, cutnext));
+                const uint32_t idin = (j & 1) ? (id2[j / 2] >> 16) : (id2[j / 2] & 0xFFFFu);
+                const uint32_t f1 = LDS16B(par_b + 2u * idin), f2 = LDS16B(par_b + 2u * own);
+                uint32_t m_other = (0u - f1) & 0xFu; // two-site: all four bits follow the one cluster
+                if constexpr (HAS_LONG) { // longitudinal op: both bits of its variable
+                    const uint64_t twom = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mkv, 4 * j + 2) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mkv, 4 * j + 3) << 32);
+                    m_other &= sel64(twom, vgpr_copy_u32(0xFu), vgpr_copy_u32(0x5u));
+                }
+                bpend[j] = sel64(cutm, f1 | (f2 << 2), m_other);
+                cutnext += (uint32_t)popc64(cutm);
+            }
+        }
+        if (pbeg < pend) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) fb[pprev + (uint32_t)(j * 64 + lane)] = (uint8_t)bpend[j];
+        }
+    } else
     {
         uint32_t cutnext = N + cutbase;
         const uint32_t E1 = B.E + 1u;
@@ -466,6 +544,7 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
     for (uint32_t i = tid; i < nwords; i += NT) B.state[(size_t)r * nwords + i] = LDSW(L.o_state, i);
     if (tid == 0) {
         B.epoch[r] = epoch;
+        if (DEFER) B.pend[r] = 1u; // (behind the barriers above: every wave's flip bytes are on their way; the kernel boundary orders them)
         if (A.out_u32) A.out_u32[r] = nclusters;
         uint64_t *acc = B.acc + (size_t)B.acc_row[r] * 8;
         acc[0] += a0; acc[1] += a1; acc[2] += a2; acc[3] += a3; acc[4] += (uint64_t)n; acc[6] += a6;

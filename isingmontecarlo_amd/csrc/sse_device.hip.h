@@ -85,6 +85,12 @@ struct DevBatch {
     uint32_t bond_stride; // 0, or Nb when every replica has its own bond table / cumulative weights (per-replica couplings)
     const double *wtot_r; // [R] per-replica total weight (bond_stride != 0)
     const uint32_t *adj_start, *adj; // [N+1], [2E] bonds_for_var (make_classical_bonds, qmc_ising.rs:421-432)
+    // deferred cluster flips (sse_cluster.hip.h -> sse_fast.hip.h): instead of rewriting the op-string, the cluster update leaves one
+    // byte per slot — the xor mask of the word's four state bits — and the diagonal pass of the next timestep applies it while it
+    // streams the string anyway (the apply pass was bound by its 10 B/slot of memory traffic).  pend[r] = 1: replica r's string
+    // in HBM is still the one BEFORE the flips; every other consumer of the strings goes through materialize_kernel first.
+    uint8_t *flipb;       // [R][stride] or null
+    uint32_t *pend;       // [R]
     uint32_t rvb_growers; // RVB: attempts grown side by side (0 = one at a time on wave 0)
     uint32_t dbg_flags;   // diagnostic builds only
     unsigned long long *dbg; // [R][16] phase durations in 10-ns ticks (diagnostic builds only, -DSSE_PHASE_TIMING)
@@ -119,6 +125,8 @@ struct SweepArgs {
     uint32_t rvb_updates; // RVB attempts per step (0 = (N+1)/2, qmc_ising.rs:711)
     uint32_t *out_u32; // optional per-replica output (n_clusters / loop length / RVB successes) of the LAST step
     uint32_t only_flagged; // 1 = run only the replicas flagged in DevBatch::aux (left over by sse::cluster_kernel) and clear their flags
+    uint32_t defer_flips;  // sse::cluster_kernel: leave the flips as one byte per slot (DevBatch::flipb) instead of applying them;
+                           // sse::sweep_fast_kernel: apply the pending flip bytes of a replica while loading its string
 };
 
 // scalar add that the optimiser may not hoist or merge: the ten round keys are wave-uniform and loop-invariant,

@@ -92,12 +92,20 @@ __device__ __forceinline__ uint32_t fast_entry(const DevBatch &B, uint32_t b, ui
 // their net accepted moves, which the rounds exchange anyway) and at earlier rows / lanes of this wave (wave masks).
 template <int K, bool LABEL, bool COMPACT>
 __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L, const FastLds &F, uint32_t r, const Rng &rng, double beta,
-                                              uint32_t M, int &n_io, int &ntrans_io, uint32_t &gr) {
+                                              uint32_t M, int &n_io, int &ntrans_io, uint32_t &gr, uint32_t fbmask) {
     constexpr int W = 4, NT = W * 64;
     constexpr uint32_t TS = (uint32_t)(NT * K);
     static_assert(K == 2 || K == 4, "rows p and p + 64 share one Philox call");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *ops = B.ops + (size_t)r * B.stride;
+    // pending cluster flips of this replica (fbmask = 0xFF) are applied to every word as it is loaded: one byte per slot, the xor
+    // mask of its four state bits (0 for empty slots and beyond the cutoff); fbmask = 0: the string in HBM is current
+    // (the byte load is unconditional — a branch would put it into a basic block of its own and cost the prefetch its counted
+    // waits; without pending flips it reads bytes of the string itself and the mask drops them)
+    const uint8_t *flipb = (fbmask ? B.flipb : reinterpret_cast<const uint8_t *>(B.ops)) + (size_t)r * B.stride;
+    auto ld_word = [&](uint32_t idx) -> uint32_t {
+        return row_ld(ops, idx) ^ ((uint32_t)*reinterpret_cast<const uint8_t *>(reinterpret_cast<const char *>(flipb) + (size_t)idx) & fbmask);
+    };
     const uint32_t N = B.N, Nb = B.Nb, E = B.E;
     for (uint32_t i = tid; i < N; i += NT) LDSW(F.o_spin, i) = ((LDSW(L.o_state, i >> 5) >> (i & 31)) & 1u) * 0x01010101u;
     if constexpr (LABEL) {
@@ -132,7 +140,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
 
     uint32_t wnext[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, (uint32_t)(wave * 64 * K + j * 64 + lane));
+    for (int j = 0; j < K; ++j) wnext[j] = ld_word((uint32_t)(wave * 64 * K + j * 64 + lane));
     propagate(wnext, m_later);
     __syncthreads();
     const uint32_t lane2 = 2u * (uint32_t)lane;
@@ -246,7 +254,7 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         {
             const uint32_t pn = (tile + 1 < ntiles ? pbase + TS : pbase);
 #pragma unroll
-            for (int j = 0; j < K; ++j) wnext[j] = row_ld(ops, pn + (uint32_t)(j * 64));
+            for (int j = 0; j < K; ++j) wnext[j] = ld_word(pn + (uint32_t)(j * 64));
         }
         const bool partial = tile * TS + TS > M; // wave-uniform: only the last tile can hold slots >= M
 
@@ -519,11 +527,14 @@ __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArg
     uint32_t M = B.cutoff[r], err = B.err[r], gr = 0, last_out = 0;
     uint64_t epoch = B.epoch[r];
     uint64_t a4 = 0, a5 = 0;
+    // pending cluster flips of this replica: applied by the first diagonal pass of the launch (the host passes defer_flips only
+    // to launches that start with one)
+    const uint32_t fbmask = (A.defer_flips && B.flipb && (A.domask & SSE_DO_DIAG) && !err && B.pend[r]) ? 0xFFu : 0u;
     for (uint64_t step = 0; step < A.nsteps; ++step) {
         if (err) break;
         if (A.domask & SSE_DO_DIAG) {
             const Rng rng = make_rng(B, r, epoch);
-            diagonal_fast<K, LABEL, COMPACT>(B, L, F, r, rng, beta, M, n, ntrans, gr);
+            diagonal_fast<K, LABEL, COMPACT>(B, L, F, r, rng, beta, M, n, ntrans, gr, step == 0 ? fbmask : 0u);
             epoch++;
             a5 += M;
             if (A.domask & SSE_DO_GROW) { // qmc_ising.rs:786, qmc_runner.rs:197
@@ -548,6 +559,7 @@ __global__ __launch_bounds__(256, 4) void sweep_fast_kernel(DevBatch B, SweepArg
     for (uint32_t i = tid; i < 2 * SSE_MAX_CHUNKS; i += NT) B.chunks[(size_t)r * 2 * SSE_MAX_CHUNKS + i] = LDSW(L.o_chn, i);
     if (tid == 0) {
         B.n[r] = (uint32_t)n; B.ntrans[r] = (uint32_t)ntrans; B.cutoff[r] = M; B.err[r] = err; B.epoch[r] = epoch;
+        if (fbmask && A.nsteps) B.pend[r] = 0u; // the diagonal pass rewrote the whole string with the flips applied
         if (A.out_u32) A.out_u32[r] = last_out;
         uint64_t *acc = B.acc + (size_t)B.acc_row[r] * 8;
         acc[4] += a4; acc[5] += a5;

@@ -778,7 +778,7 @@ def test_64x64_cold_end_runs_on_the_hbm_union_find_and_matches(oracle):
 # it leaves to the general kernel (no cut / no op at high temperature, ids beyond the union-find planned before the first
 # launch), and the same runs through the general kernel only (CFG_NO_LEAN_CLUSTER) for the A-B switch.
 @pytest.mark.parametrize("k", [0, 2])
-@pytest.mark.parametrize("nolean", [False, True])
+@pytest.mark.parametrize("nolean", [False, True, "inplace"])  # "inplace": the dedicated kernel without deferred flips
 @pytest.mark.parametrize("name,edges,gamma,h,beta,cut0", [
     ("ferro16", lat.two_d_ferro(16), 1.0, 0.0, 4.0, 256),
     ("ferro8_long", lat.two_d_ferro(8), 1.0, 0.25, 3.0, 64),
@@ -788,10 +788,11 @@ def test_64x64_cold_end_runs_on_the_hbm_union_find_and_matches(oracle):
 def test_dedicated_cluster_kernel(oracle, name, edges, gamma, h, beta, cut0, nolean, k):
     import isingmontecarlo_amd as im
     R = 12
-    g, m, reps = make_pair(oracle, edges, gamma, h, cut0, 1 << 15, 4711, R, k=k, cfg_flags=im.CFG_NO_LEAN_CLUSTER if nolean else 0)
+    cfgf = {False: 0, True: im.CFG_NO_LEAN_CLUSTER, "inplace": im.CFG_NO_DEFERRED_FLIPS}[nolean]
+    g, m, reps = make_pair(oracle, edges, gamma, h, cut0, 1 << 15, 4711, R, k=k, cfg_flags=cfgf)
     g.run(12, beta, sampling_freq=2)
     oracle.batch_timesteps(reps, 12, [beta] * R, 2, 0)
-    assert g.launch_info()["lean_cluster"] == (not nolean)
+    assert g.launch_info()["lean_cluster"] == (nolean is not True)
     assert_same(g, reps, f"{name} timesteps")
     for it in range(6):
         g.single_diagonal_step(beta)
