@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-lds-tables", action="store_true")
+    ap.add_argument("--global-tables", action="store_true", help="force the per-variable tables into HBM (with --waves: that wave count in the HBM-table mode)")
     ap.add_argument("--no-loop", action="store_true")
     ap.add_argument("--rvb", action="store_true", help="configs[2]: QmcIsingGraph::timestep with RVB sweeps (no directed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -190,7 +191,8 @@ def main():
         cap = 1 << int(np.ceil(np.log2(2.0 * n_est + 4 * nsite)))
         flags &= ~im.FLAG_LOOP
         g = im.QmcIsingGraph(edges, 1.0, 0.1, nsite, args.seed, nreplicas=R, capacity=cap, replica_offset=rank * R,
-                             device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k, couplings=couplings)
+                             device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k, couplings=couplings,
+                             cfg_flags=(im.CFG_GLOBAL_TABLES | im.CFG_NO_LDS_TABLES) if args.global_tables else 0)
     else:
         g = im.QmcIsingGraph(edges, 1.0, 0.0, L * L, args.seed, nreplicas=R, capacity=cap,
                              replica_offset=rank * R, device=local_rank, waves_per_replica=args.waves, slots_per_lane=args.k,

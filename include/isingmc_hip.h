@@ -65,6 +65,9 @@ extern "C" {
                                            LDS edge tables, N <= 4095, default wave counts) applies (testing / A-B timing) */
 #define ISINGMC_CFG_NO_DEFERRED_FLIPS 512u /* the dedicated cluster kernel rewrites the op-strings itself instead of leaving one flip byte per slot
                                              for the diagonal launch of the next timestep to apply (testing / A-B timing) */
+#define ISINGMC_CFG_NO_PM_DECODE 1024u /* large disorder batches (per-replica coupling SIGNS, uniform |J| and fields, tables in HBM) decode
+                                          bonds through the per-replica 16-byte records like any other model instead of the shared compact edge
+                                          table + per-replica sign bits (testing / A-B timing) */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 

@@ -36,6 +36,7 @@ struct isingmc_batch {
     bool compact = false;               // ... and it writes the dense op list for the cluster update that follows in the same timestep
     bool lite = false;                  // ... or (experimental) labels the segments for the cluster update that follows in the same timestep
     bool fused_launch = false;          // ISINGMC_CFG_FUSED_LAUNCH: whole timesteps in one kernel (no diagonal-only launches)
+    size_t lds_bytes_pm_diag = 0;       // +-J decode: LDS of the diagonal launch with its per-wave spin bytes in LDS (0 = they do not fit: mode 4 there too)
     bool lean_cluster = false;          // cluster (+ free spins + sampling) launches use sse_cluster.hip.h when their ids fit its LDS union-find
     bool last_lean = false;             // ... and the last such launch did
     bool defer = false;                 // ... leaving its flips as one byte per slot for the next (trimmed) diagonal launch to apply
@@ -230,10 +231,11 @@ static int ensure_materialized(isingmc_batch *b) {
     return ISINGMC_OK;
 }
 
-static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, bool tg = false) {
+static size_t lds_fixed_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, bool tg = false, uint32_t pm_words = 0) {
     // mirrors Lds<W>::carve up to and including o_cl: state, touched bits, touched bytes, round buffers, misc, chunk counters,
     // edge table, per-wave rank tables (u16) and marker tables (u8); with the tables in HBM (tg) only the bit arrays remain
-    if (tg) return (size_t)nwords * 2 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges;
+    // (+ the coupling signs of the +-J decode)
+    if (tg) return (size_t)nwords * 2 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges + pm_words;
     return (size_t)nwords * 2 + ((size_t)N + 3) / 4 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + ledges + ((size_t)W * N + 1) / 2 + ((size_t)W * N + 3) / 4;
 }
 // dynamic LDS of the fast diagonal-pass launch (mirrors Lds<4>::carve up to o_cur, then FastLds: sse_fast.hip.h fast_carve)
@@ -243,7 +245,8 @@ static size_t fast_lds_bytes(uint32_t N, uint32_t nwords, uint32_t E, uint32_t N
     if (words < o_edges + E) words = o_edges + E; // the directed loop behind the pass stages the compact edge table there
     return (4 * words + 7) & ~(size_t)7;
 }
-static bool is_tg(const isingmc_batch *b) { return b->mode == SSE_MODE_GLOBAL_TABLES; }
+static bool is_tg(const isingmc_batch *b) { return b->mode == SSE_MODE_GLOBAL_TABLES || b->mode == SSE_MODE_PM_GLOBAL_TABLES; }
+static bool is_pm(const isingmc_batch *b) { return b->mode == SSE_MODE_PM_GLOBAL_TABLES; }
 // dynamic LDS of the diagonal-pass launch: the fixed regions up to the per-wave tables, which it uses as [W][N] spin bytes
 static size_t diag_lds_bytes(const isingmc_batch *b) {
     const size_t words = is_tg(b) ? b->lds_fixed_words_ : b->lds_fixed_words_ - ((size_t)b->W * b->dev.N + 1) / 2;
@@ -257,7 +260,7 @@ static size_t diag_lds_bytes(const isingmc_batch *b) {
 struct LdsPlan { uint32_t W, ufcap; size_t lds_bytes; bool all_ids_fit; };
 static LdsPlan plan_lds(const isingmc_batch *b, uint32_t W) {
     const DevBatch &D = b->dev;
-    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u, is_tg(b));
+    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u, is_tg(b), is_pm(b) ? D.pm_words : 0u);
     const size_t ids_max = (size_t)W * D.N + D.cap;
     const size_t want = (size_t)W * D.N + b->max_ntrans + b->max_ntrans / 16 + 384;
     size_t ids = want;
@@ -501,6 +504,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         const bool use_compact = use_fast && !use_label && b->compact && (A.domask & SSE_DO_CLUSTER) && !(A.domask & SSE_DO_RVB);
         // the diagonal launch needs the fixed regions up to the per-wave tables, which it uses as [W][N] bytes
         ld.lds_bytes = use_fast ? (use_label ? b->lds_bytes_fast_label : b->lds_bytes_fast) : diag_lds_bytes(b);
+        if (is_pm(b) && b->lds_bytes_pm_diag) { ld.mode = SSE_MODE_PM_LDS_TABLES; ld.lds_bytes = b->lds_bytes_pm_diag; } // (the cluster tables stay in HBM)
         const uint32_t rest = A.domask & ~diag_bits;
         constexpr size_t MAX_TIMED = 256;
         const size_t want_ev = 4 * (size_t)(nsteps < MAX_TIMED ? nsteps : MAX_TIMED);
@@ -786,7 +790,7 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     }
     if (TG && CL) { b->err = "ISINGMC_CFG_GLOBAL_TABLES needs the general bond table: combine it with ISINGMC_CFG_NO_LDS_TABLES"; return fail(ISINGMC_EINVAL); }
     if (TG && K == 2) K = 4;
-    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges, TG);
+    const size_t fixed = lds_fixed_words(W, D.N, D.nwords, ledges, TG, TG ? (D.E + 31u) / 32u : 0u); // (room for the +-J decode's signs, decided below)
     if (fixed + 64 > total_words) { b->err = "model too large: the spin-state bit arrays alone exceed LDS"; return fail(ISINGMC_ENOTIMPL); }
     // off-diagonal launches may use their own wave count (see run()): explicit, or decided per launch (then up to 16)
     uint32_t W_off = cfg->waves_offdiag;
@@ -801,6 +805,19 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
     const uint32_t Wmax = W_off ? (W_off > W ? W_off : W) : ((W < 16 && w16_possible) ? 16u : (w8_possible ? 8u : W));
     const size_t ids_max = (size_t)Wmax * D.N + D.cap;
     b->W = W; b->K = K; b->mode = TG ? SSE_MODE_GLOBAL_TABLES : (CL ? SSE_MODE_LDS_EDGES : SSE_MODE_GENERAL); b->W_off = W_off;
+    // "+-J" decode for large disorder batches (BASELINE configs[4]): every replica its own coupling signs on one graph with uniform
+    // |J|, Gamma, h.  The general decode fetches a 16-byte record per op and pass from a per-replica table of megabytes — one random
+    // HBM sector each time, in a mode that is bound by exactly those; here the variables come from the shared compact edge table
+    // (L2-resident), the sign from 12 KB of LDS.  Default geometry only.
+    const bool PMJ = TG && perJ && D.uniformJ && !generic && W == 4 && K == 4 && D.N <= SSE_CE_MAX_VARS && !cfg->transverse_r && !cfg->longitudinal_r &&
+                     !(cfg->flags & ISINGMC_CFG_NO_PM_DECODE);
+    if (PMJ) {
+        b->mode = SSE_MODE_PM_GLOBAL_TABLES;
+        D.pm_words = (D.E + 31u) / 32u;
+        // the diagonal launch keeps its per-wave spin bytes in LDS when W * N bytes fit next to the small arrays
+        const size_t words = (size_t)D.nwords * 2 + 4 * W + 16 + 2 * SSE_MAX_CHUNKS + D.pm_words + ((size_t)W * D.N + 3) / 4;
+        b->lds_bytes_pm_diag = (words + 64 <= total_words && !(cfg->flags & ISINGMC_CFG_GLOBAL_TABLES)) ? ((4 * words + 7) & ~(size_t)7) : 0;
+    }
     { // chunk grid and row stride: one function (also exported for the CPU-side bound checks of tests/test_abi_cpu.py)
         uint32_t geo[4];
         if (isingmc_plan_geometry(D.cap, W, K, Wmax, geo) != ISINGMC_OK) { b->err = "capacity too large for the row stride"; return fail(ISINGMC_EINVAL); }
@@ -879,6 +896,16 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         if (hipMemcpy(dew, ew.data(), sizeof(double) * D.E, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(dce, ce.data(), sizeof(uint32_t) * D.E, hipMemcpyHostToDevice) != hipSuccess) { b->err = "edge table upload failed"; return fail(ISINGMC_ENODEVICE); }
         D.edge_w = dew; D.edges_compact = dce;
+    }
+    if (is_pm(b)) { // coupling signs of every bond-table row: bit e = prefers aligned (J < 0)
+        std::vector<uint32_t> sg((size_t)nH * D.pm_words, 0u);
+        for (uint32_t hI = 0; hI < nH; ++hI)
+            for (uint32_t e = 0; e < D.E; ++e)
+                if ((tab[(size_t)hI * D.Nb + e].a_info >> (SSE_INFO_SHIFT + 2)) & 1u) sg[(size_t)hI * D.pm_words + (e >> 5)] |= 1u << (e & 31);
+        uint32_t *dsg = nullptr;
+        if ((rc = dalloc(b, &dsg, sg.size(), false))) return fail(rc);
+        if (hipMemcpy(dsg, sg.data(), 4 * sg.size(), hipMemcpyHostToDevice) != hipSuccess) { b->err = "sign upload failed"; return fail(ISINGMC_ENODEVICE); }
+        D.pm_signs = dsg;
     }
     { // bonds_for_var (make_classical_bonds, qmc_ising.rs:421-432): edge order
         std::vector<uint32_t> as(D.N + 2, 0u), ad(2 * (size_t)D.E + 1), fill(D.N, 0u);

@@ -46,6 +46,9 @@ struct DevBatch {
     const uint32_t *acc_row; // [R] accumulator row of each replica
     const BondRec *bonds; // [Nb]
     const uint32_t *edges_compact; // [E] or null
+    const uint32_t *pm_signs; // [rows][pm_words]: bit e = edge e prefers aligned spins (J < 0), one row per bond-table row: the "+-J"
+                          // decode (MODE >= 3) takes a bond's variables from the shared compact edge table and only its sign from here
+    uint32_t pm_words;    // words per row of pm_signs = ceil(E / 32)
     const double *edge_w; // [E] 2|J|
     const double *cumw;   // [Nb] heat-bath cumulative weights
     double wtot;
@@ -134,7 +137,10 @@ struct SweepArgs {
 // spilled to vector lanes and read back with v_readlane on every use); one s_add per key and call is cheaper
 __device__ __forceinline__ uint32_t philox_bump(uint32_t k, uint32_t w) {
     uint32_t r;
-    asm volatile("s_add_u32 %0, %1, %2" : "=s"(r) : "s"(k), "s"(w) : "scc");
+    // (readfirstlane: free when the key already sits in a scalar register; under scalar-register pressure the allocator may hold
+    // the uniform key in a vector register, which the "s" constraint alone does not move back)
+    const uint32_t ks = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    asm volatile("s_add_u32 %0, %1, %2" : "=s"(r) : "s"(ks), "s"(w) : "scc");
     return r;
 }
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -236,25 +242,30 @@ struct Lds {           // word offsets into lds_raw
     uint32_t o_chn;    // [SSE_MAX_CHUNKS] occupied slots per chunk
     uint32_t o_chtr;   // [SSE_MAX_CHUNKS] transverse ops per chunk
     uint32_t o_edges;  // [E]           compact edge table (CL mode only)
+    uint32_t o_signs;  // [pm_words]    this replica's coupling signs (+-J decode only)
     uint32_t o_cur;    // [W][N] u16    per wave: rank+1 (within the wave's range) of the latest cut on each variable
     uint32_t o_cl;     // [W][N] u8     per wave: 1 + rank inside the current sub-round of a cut on the variable (0 = none)
     uint32_t o_frozen; // [ufwords]     bit per id: segment holds a longitudinal op
     uint32_t o_froot;  // [ufwords]     bit per id: root is frozen
     uint32_t o_parent; // [ufcap] u16 (the LDS union-find is only used when every id fits 16 bits)
-    __device__ __forceinline__ void carve(uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges, uint32_t has_long, bool tg = false) {
+    // diag_only: the launch runs the diagonal pass (+ directed loop) alone and its per-wave spin BYTES are the only per-variable
+    // table (large models whose cluster tables live in HBM can still keep these in LDS)
+    __device__ __forceinline__ void carve(uint32_t N, uint32_t nwords, uint32_t ufcap, uint32_t ledges, uint32_t has_long, bool tg = false,
+                                          uint32_t pm_words = 0, bool diag_only = false) {
         uint32_t base = 0;
         o_state = base; base += nwords;
         o_touch = base; base += nwords;
         if (tg) N = 0; // MODE 2: the per-variable tables live in HBM (Tab<true>), only the bit arrays stay in LDS
-        o_touch8 = base; base += (N + 3) / 4;
+        o_touch8 = base; base += diag_only ? 0u : (N + 3) / 4;
         o_tot = base; base += 2 * W;
         o_chg = base; base += 2 * W;
         o_misc = base; base += 16;
         o_chn = base; base += SSE_MAX_CHUNKS;
         o_chtr = base; base += SSE_MAX_CHUNKS;
         o_edges = base; base += ledges;
-        o_cur = base; base += (W * N + 1) / 2;
-        o_cl = base; base += (W * N + 3) / 4;
+        o_signs = base; base += pm_words;
+        o_cur = base; base += diag_only ? (W * N + 3) / 4 : (W * N + 1) / 2;
+        o_cl = base; base += diag_only ? 0u : (W * N + 3) / 4;
         o_frozen = base; base += has_long ? (ufcap + 31) / 32 : 0u;
         o_froot = base; base += has_long ? (ufcap + 31) / 32 : 0u;
         o_parent = base;
@@ -301,11 +312,35 @@ __device__ __forceinline__ Tab<TG> make_tab(const DevBatch &B, const Lds<W> &L, 
     return T;
 }
 // MODE of a kernel: how bonds are decoded and where the per-variable tables live
-enum { SSE_MODE_GENERAL = 0, SSE_MODE_LDS_EDGES = 1, SSE_MODE_GLOBAL_TABLES = 2 };
+// (3 / 4: the "+-J" decode — every replica its own coupling SIGNS on a shared graph with uniform |J| and fields: a bond's variables
+// come from the shared compact edge table in global memory (L2-resident), its sign from a per-replica bit array in LDS, its weight
+// from three scalars; nothing per replica is fetched from HBM to decode an op.  3 = per-variable tables in LDS (diagonal launches
+// only), 4 = in HBM like mode 2)
+enum { SSE_MODE_GENERAL = 0, SSE_MODE_LDS_EDGES = 1, SSE_MODE_GLOBAL_TABLES = 2, SSE_MODE_PM_LDS_TABLES = 3, SSE_MODE_PM_GLOBAL_TABLES = 4 };
 
 enum { MISC_NCLUST = 0, MISC_ANYFROZEN = 1, MISC_LOOP_A = 2, MISC_LOOP_B = 3, MISC_LOOP_C = 4, MISC_LOOP_D = 5 };
 
-template <bool CL, int W>
+// The 16-byte bond record of bond b: loaded from this replica's table (general decode) or, for the +-J decode, put together from
+// the shared compact edge table, the replica's sign bits in LDS and the uniform weights — everything downstream is the same code.
+template <bool PM, int W>
+__device__ __forceinline__ uint4 bond_rec(const DevBatch &B, const Lds<W> &L, uint32_t b) {
+    if constexpr (PM) {
+        const bool two = b < B.E;
+        const uint32_t eb = two ? b : 0u;
+        const uint32_t e = B.edges_compact[eb];
+        const uint32_t sgn = (LDSW(L.o_signs, eb >> 5) >> (eb & 31u)) & 1u;
+        const uint32_t s1 = b - B.E;
+        const bool tr = s1 < B.N;
+        const uint32_t a = two ? (e & SSE_CE_VAR_MASK) : (tr ? s1 : s1 - B.N);
+        const uint32_t kp = two ? (SSE_BOND_TWO_SITE | (sgn << 2)) : (tr ? SSE_BOND_TRANSVERSE : (SSE_BOND_LONGITUDINAL | (B.hpos << 2)));
+        const double w = two ? B.wJ : (tr ? B.gamma : B.wh);
+        return make_uint4(a | (kp << SSE_INFO_SHIFT), two ? ((e >> 15) & SSE_CE_VAR_MASK) : SSE_NO_VAR, (uint32_t)__double2loint(w), (uint32_t)__double2hiint(w));
+    } else {
+        return *reinterpret_cast<const uint4 *>(B.bonds + b);
+    }
+}
+
+template <bool CL, int W, bool PM = false>
 __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, uint32_t b) {
     Bd d;
     if constexpr (CL) {
@@ -326,7 +361,7 @@ __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, ui
         const int hlo = __builtin_amdgcn_readfirstlane(__double2loint(B.wh)), hhi = __builtin_amdgcn_readfirstlane(__double2hiint(B.wh));
         d.w = __hiloint2double(two ? jhi : (tr ? ghi : hhi), two ? jlo : (tr ? glo : hlo));
     } else {
-        const uint4 q = *reinterpret_cast<const uint4 *>(B.bonds + b);
+        const uint4 q = bond_rec<PM, W>(B, L, b);
         d.a = q.x & SSE_VAR_MASK; d.c = q.y; d.kp = q.x >> SSE_INFO_SHIFT;
         d.w = __hiloint2double((int)q.w, (int)q.z);
     }
@@ -388,7 +423,7 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t tile, int wave, int j, int 
 // Per slot and round the work is: one int->f64 convert, one f64 multiply, two f64 compares (written straight to
 // wave masks), the mask algebra on the scalar unit, and four mbcnt for the prefix counts.  All compares are the
 // IEEE f64 expressions of oracle/sse_oracle.c (built with -ffp-contract=off on both sides).
-template <int W, int K, bool CL, bool HB, bool TG>
+template <int W, int K, bool CL, bool HB, bool TG, bool PM = false>
 __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double beta, uint32_t M,
                               int &n_io, int &ntrans_io, uint32_t &gr) {
     constexpr int NT = W * 64;
@@ -430,7 +465,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
             va = fa ? (s1 < B.N ? s1 : s1 - B.N) : 0u;
             vc = va;
         } else {
-            const Bd d = decode_bond<CL, W>(B, L, (fa | fc) ? sse_op_bond(wd) : 0u);
+            const Bd d = decode_bond<CL, W, PM>(B, L, (fa | fc) ? sse_op_bond(wd) : 0u);
             va = d.a; vc = d.c != SSE_NO_VAR ? d.c : d.a;
         }
         return fa;
@@ -535,7 +570,7 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
                 const uint32_t p = slot_of<W, K>(tile, wave, j, lane);
                 const uint32_t wd = word[j];
                 pre_b[j] = draw_bond(j, p, wd, wd != 0u, (p < pM) & (wd == 0u), pre_r0[j], pre_r1[j]);
-                pre_rec[j] = *reinterpret_cast<const uint4 *>(B.bonds + pre_b[j]);
+                pre_rec[j] = bond_rec<PM, W>(B, L, pre_b[j]);
             }
         }
 #pragma unroll
@@ -858,7 +893,7 @@ __device__ __forceinline__ void uf_union_wave(const UFA<G> &uf, uint32_t a, uint
 // B.cpos) instead of the padded op-string: the same p-ordered stream without its empty slots (a third of all slots at
 // M = 1.5 n), every lane of every row useful.  Ranges are still bounded by chunks of the padded string — their occupied counts
 // (o_chn) give the corresponding ranges of the list — and the segment ids still land at the ops' slots (segs[cpos]).
-template <int W, int K, bool CL, bool APPLY, bool G, bool TG, bool COMPACT = false>
+template <int W, int K, bool CL, bool APPLY, bool G, bool TG, bool COMPACT = false, bool PM = false>
 __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<G> &uf,
                                              uint32_t C) {
     static_assert(!COMPACT || (!APPLY && !G && !TG), "the dense list feeds the build scan of the LDS union-find path");
@@ -917,7 +952,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
         uint4 pre_rec[K]; // general bond table: request the tile's K records together (see diagonal_pass)
         if constexpr (!CL) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) pre_rec[j] = *reinterpret_cast<const uint4 *>(B.bonds + (word[j] ? sse_op_bond(word[j]) : 0u));
+            for (int j = 0; j < K; ++j) pre_rec[j] = bond_rec<PM, W>(B, L, word[j] ? sse_op_bond(word[j]) : 0u);
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -1057,7 +1092,7 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
 // Apply pass of the LDS union-find path (cluster.rs:139-167): every slot's segment ids were stored by the build
 // scan, flip bits sit in the (flattened) parent table, so the slots can be rewritten in any order: plain strided
 // streaming, no ordered scan.  Input bits flip with the incoming segment, output bits with the outgoing one.
-template <int W, int K, bool CL, bool G = false>
+template <int W, int K, bool CL, bool G = false, bool PM = false>
 __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<G> &uf) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
@@ -1080,7 +1115,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
             for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, pn0 + (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, pn0 + (uint32_t)(j * NT + tid)); if constexpr (G) tn[j] = row_ld(segs2, pn0 + (uint32_t)(j * NT + tid)); }
         }
         uint32_t second[K]; // general bond table: the second variable of the tile's K bonds, requested together
-        if constexpr (!CL) {
+        if constexpr (!CL && !PM) {
 #pragma unroll
             for (int j = 0; j < K; ++j) second[j] = reinterpret_cast<const uint32_t *>(B.bonds + (wd[j] ? sse_op_bond(wd[j]) : 0u))[1];
         }
@@ -1091,7 +1126,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
             // segment ids of empty slots are stale: read a safe index
             const uint32_t fa = uf.get(nonempty ? (G ? sg[j] : (sg[j] & 0xFFFFu)) : 0u), fb = uf.get(nonempty ? (G ? sh[j] : (sg[j] >> 16)) : 0u);
             bool two;
-            if constexpr (CL) two = nonempty & (sse_op_bond(w) < B.E);
+            if constexpr (CL || PM) two = nonempty & (sse_op_bond(w) < B.E);
             else two = nonempty & (second[j] != SSE_NO_VAR);
             // two-site: both legs of variable a carry fa, both legs of variable c carry fb;
             // single-site: the input leg carries fa (incoming segment), the output leg fb (outgoing segment)
@@ -1106,7 +1141,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
 
 // Cluster update.  Reference: ClusterUpdater::flip_each_cluster_rng (qmc_traits/cluster.rs:36-172) with the
 // longitudinal weight function of qmc_ising.rs:759-775.  Returns the number of clusters.
-template <int W, int K, bool CL, bool UF_GLOBAL, bool TG, bool LITE = false, bool COMPACT = false>
+template <int W, int K, bool CL, bool UF_GLOBAL, bool TG, bool LITE = false, bool COMPACT = false, bool PM = false>
 __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, double prob,
                                                  uint32_t M, int n, int ntrans, uint32_t &gr, uint32_t &err) {
     static_assert(UF_GLOBAL || !TG, "tables in HBM imply the HBM union-find");
@@ -1172,7 +1207,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     __syncthreads();
     // ---- build: label legs with segment ids, union through non-boundary ops ----
     SSE_STAMP(0);
-    cluster_scan<W, K, CL, false, UF_GLOBAL, TG, COMPACT>(B, L, r, M, uf, C);
+    cluster_scan<W, K, CL, false, UF_GLOBAL, TG, COMPACT, PM>(B, L, r, M, uf, C);
     // touched bytes -> bits (read by the coins, the p=0 state update and the free-spin pass, all behind later barriers)
     for (uint32_t i = tid; i < nwords; i += NT) {
         uint32_t bits = 0;
@@ -1290,9 +1325,9 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     SSE_STAMP(4);
     // ---- apply (cluster.rs:139-167) ----
     if constexpr (UF_GLOBAL) {
-        if (B.segs2) cluster_apply_cached<W, K, CL, true>(B, L, r, M, uf); // both ids of every slot were stored by the build scan
-        else cluster_scan<W, K, CL, true, UF_GLOBAL, TG>(B, L, r, M, uf, C);  // (a replica that outgrew the LDS union-find before the host planned for it)
-    } else cluster_apply_cached<W, K, CL>(B, L, r, M, uf);
+        if (B.segs2) cluster_apply_cached<W, K, CL, true, PM>(B, L, r, M, uf); // both ids of every slot were stored by the build scan
+        else cluster_scan<W, K, CL, true, UF_GLOBAL, TG, false, PM>(B, L, r, M, uf, C);  // (a replica that outgrew the LDS union-find before the host planned for it)
+    } else cluster_apply_cached<W, K, CL, false, PM>(B, L, r, M, uf);
     SSE_STAMP(5);
     // p=0 state follows the placeholder segment of each touched variable
     for (uint32_t i = tid; i < nwords; i += NT) {
@@ -1306,7 +1341,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
 }
 
 // touched-variable scan for launches that flip free spins without a preceding cluster pass
-template <int W, bool CL>
+template <int W, bool CL, bool PM = false>
 __device__ __forceinline__ void touch_scan(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M) {
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
@@ -1320,7 +1355,7 @@ __device__ __forceinline__ void touch_scan(const DevBatch &B, const Lds<W> &L, u
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!wd[j]) continue;
-            const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
+            const Bd d = decode_bond<CL, W, PM>(B, L, sse_op_bond(wd[j]));
             atomicOr(&LDSW(L.o_touch, d.a >> 5), 1u << (d.a & 31));
             if (d.c != SSE_NO_VAR) atomicOr(&LDSW(L.o_touch, d.c >> 5), 1u << (d.c & 31));
         }
@@ -1353,7 +1388,7 @@ __device__ __forceinline__ void free_spin_pass(const DevBatch &B, const Lds<W> &
 //   get_nth_p (:76-87, an O(n) list walk)        -> tile-wise ballot/popcount rank search
 //   get_next/previous_p_for_rel_var (:51-54)     -> tile-wise search along the worldline direction
 // Returns the number of vertices visited.
-template <int W, bool CL>
+template <int W, bool CL, bool PM = false>
 __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, const Rng &rng, uint32_t M, int n, uint32_t &gr,
                               uint32_t &err) {
     constexpr int NT = W * 64;
@@ -1406,7 +1441,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
     if (p0 == 0xFFFFFFFFu) { err = 2u; return 0u; } // n inconsistent with the op-string
     uint32_t rel0, side0;
     {
-        const Bd d0 = decode_bond<CL, W>(B, L, sse_op_bond(ops[p0]));
+        const Bd d0 = decode_bond<CL, W, PM>(B, L, sse_op_bond(ops[p0]));
         const uint32_t k0 = d0.c != SSE_NO_VAR ? 2u : 1u;
         rel0 = __umulhi(o0.y, k0);
         side0 = (o0.z >> 31) ? 0u : 1u; // gen() true -> Inputs (directed_loop.rs:153-157)
@@ -1418,7 +1453,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
         // ---- vertex update by thread 0 ----
         if (tid == 0) {
             const uint32_t word = ops[p];
-            const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(word));
+            const Bd d = decode_bond<CL, W, PM>(B, L, sse_op_bond(word));
             const uint32_t k = d.c != SSE_NO_VAR ? 2u : 1u;
             uint32_t in_e = sse_op_in(word), out_e = sse_op_out(word);
             if (side == 0u) in_e ^= 1u << rel; else out_e ^= 1u << rel;
@@ -1472,7 +1507,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
             for (int j = U - 1; j >= 0; --j) {
                 bool match = false;
                 if (wd[j]) {
-                    const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd[j]));
+                    const Bd d = decode_bond<CL, W, PM>(B, L, sse_op_bond(wd[j]));
                     match = d.a == var || d.c == var;
                 }
                 const uint64_t mm = sse_ballot(match);
@@ -1488,7 +1523,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
         uint32_t q = forward ? p + found : p + M - found;
         const bool wrapped = forward ? (q >= M) : (found > p);
         if (q >= M) q -= M;
-        const Bd dq = decode_bond<CL, W>(B, L, sse_op_bond(ops[q]));
+        const Bd dq = decode_bond<CL, W, PM>(B, L, sse_op_bond(ops[q]));
         const uint32_t nrel = dq.a == var ? 0u : 1u;
         if (wrapped && tid == 0) { // directed_loop.rs:276-288
             const uint32_t wi = var >> 5, bi = var & 31;
@@ -1531,9 +1566,11 @@ constexpr int sse_waves_per_simd() {
 template <int W, int K, int MODE, int PHASE, int PASSES>
 __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void sweep_kernel(DevBatch B, SweepArgs A) {
     constexpr int NT = W * 64;
-    constexpr bool CL = MODE == SSE_MODE_LDS_EDGES, TG = MODE == SSE_MODE_GLOBAL_TABLES;
+    constexpr bool CL = MODE == SSE_MODE_LDS_EDGES, TG = MODE == SSE_MODE_GLOBAL_TABLES || MODE == SSE_MODE_PM_GLOBAL_TABLES;
+    constexpr bool PM = MODE == SSE_MODE_PM_LDS_TABLES || MODE == SSE_MODE_PM_GLOBAL_TABLES;
+    static_assert(MODE != SSE_MODE_PM_LDS_TABLES || PASSES == SSE_PASSES_DIAG, "mode 3 is the diagonal launch of large +-J models");
     Lds<W> L;
-    L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u, B.has_long, TG);
+    L.carve(B.N, B.nwords, B.lds_ufcap, CL ? B.E : 0u, B.has_long, TG, PM ? B.pm_words : 0u, MODE == SSE_MODE_PM_LDS_TABLES);
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
     if (A.only_flagged && !B.aux[r]) return; // (uniform per workgroup; the flag is cleared at the end, behind the barriers below)
@@ -1542,6 +1579,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         B.bonds += (size_t)hr * B.bond_stride;
         B.cumw += (size_t)hr * B.bond_stride;
         B.wtot = B.wtot_r[hr];
+        if constexpr (PM) for (uint32_t i = tid; i < B.pm_words; i += NT) LDSW(L.o_signs, i) = B.pm_signs[(size_t)hr * B.pm_words + i];
     }
     for (uint32_t i = tid; i < B.nwords; i += NT) LDSW(L.o_state, i) = B.state[(size_t)r * B.nwords + i];
     if constexpr (CL)
@@ -1558,8 +1596,8 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         if constexpr (PASSES != SSE_PASSES_OFFDIAG && PASSES != SSE_PASSES_RVB)
         if (A.domask & SSE_DO_DIAG) {
             const Rng rng = make_rng(B, r, epoch);
-            if (A.domask & SSE_DO_HEATBATH) diagonal_pass<W, K, CL, true, TG>(B, L, r, rng, beta, M, n, ntrans, gr);
-            else diagonal_pass<W, K, CL, false, TG>(B, L, r, rng, beta, M, n, ntrans, gr);
+            if (A.domask & SSE_DO_HEATBATH) diagonal_pass<W, K, CL, true, TG, PM>(B, L, r, rng, beta, M, n, ntrans, gr);
+            else diagonal_pass<W, K, CL, false, TG, PM>(B, L, r, rng, beta, M, n, ntrans, gr);
             epoch++;
             a5 += M;
             if (A.domask & SSE_DO_GROW) { // qmc_ising.rs:786, qmc_runner.rs:197
@@ -1567,7 +1605,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
                 if (want > M) { if (want > B.cap) { err = 1u; break; } M = want; }
             }
         }
-        if constexpr ((PASSES == SSE_PASSES_ALL || PASSES == SSE_PASSES_RVB) && !TG) // (RVB keeps its working set in LDS: refused by the host for MODE 2 models)
+        if constexpr ((PASSES == SSE_PASSES_ALL || PASSES == SSE_PASSES_RVB) && !TG && !PM) // (RVB keeps its working set in LDS: refused by the host for MODE 2 models)
         if (A.domask & SSE_DO_RVB) { // qmc_ising.rs:705-752
             const uint32_t updates = A.rvb_updates ? A.rvb_updates : (B.N + 1u) / 2u;
             last_out = rvb_pass<W, CL>(B, L, r, epoch, M, updates, gr, err);
@@ -1579,7 +1617,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         if constexpr (PASSES != SSE_PASSES_OFFDIAG && PASSES != SSE_PASSES_RVB)
         if (A.domask & SSE_DO_LOOP) {
             const Rng rng = make_rng(B, r, epoch);
-            last_out = loop_pass<W, CL>(B, L, r, rng, M, n, gr, err);
+            last_out = loop_pass<W, CL, PM>(B, L, r, rng, M, n, gr, err);
             epoch++;
             a4 += last_out;
             if (err) break;
@@ -1605,7 +1643,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
                 }
             }
             if (lite_done) {}
-            else if constexpr (TG) last_out = cluster_pass<W, K, CL, true, true>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
+            else if constexpr (TG) last_out = cluster_pass<W, K, CL, true, true, false, false, PM>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             else if (S_ids <= B.lds_ufcap && S_ids <= 65535u) last_out = cluster_pass<W, K, CL, false, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             else last_out = cluster_pass<W, K, CL, true, false>(B, L, r, rng, A.prob, M, n, ntrans, gr, err);
             epoch++;
@@ -1614,7 +1652,7 @@ __global__ __launch_bounds__(W * 64, (sse_waves_per_simd<W, PASSES>())) void swe
         }
         if (A.domask & SSE_DO_FREE) {
             const Rng rng = make_rng(B, r, epoch);
-            if (!(A.domask & SSE_DO_CLUSTER)) touch_scan<W, CL>(B, L, r, M);
+            if (!(A.domask & SSE_DO_CLUSTER)) touch_scan<W, CL, PM>(B, L, r, M);
             free_spin_pass<W>(B, L, rng);
             epoch++;
         }
@@ -1679,7 +1717,7 @@ hipError_t launch_k(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
         return launch_one<W, K, CL, 0, SSE_PASSES_OFFDIAG>(c, B, A);
     }
     if (c.passes == SSE_PASSES_RVB) {
-        if constexpr (CL != SSE_MODE_GLOBAL_TABLES) return launch_one<W, K, CL, 0, SSE_PASSES_RVB>(c, B, A);
+        if constexpr (CL != SSE_MODE_GLOBAL_TABLES && CL != SSE_MODE_PM_GLOBAL_TABLES) return launch_one<W, K, CL, 0, SSE_PASSES_RVB>(c, B, A);
         else return hipErrorInvalidValue;
     }
     if (c.phase && K == 4) return launch_one<W, K, CL, (K == 4 ? 1 : 0), SSE_PASSES_ALL>(c, B, A); // data-preparation symbol: default geometry only
@@ -1687,6 +1725,16 @@ hipError_t launch_k(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
 }
 template <int W>
 hipError_t launch_w(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
+    if (c.mode == SSE_MODE_PM_LDS_TABLES || c.mode == SSE_MODE_PM_GLOBAL_TABLES) { // +-J decode: the default geometry of large models only
+        if constexpr (W == 4) {
+            if (c.K != 4) return hipErrorInvalidValue;
+            if (c.mode == SSE_MODE_PM_LDS_TABLES) {
+                if (c.passes != SSE_PASSES_DIAG) return hipErrorInvalidValue;
+                return c.phase ? launch_one<4, 4, SSE_MODE_PM_LDS_TABLES, 1, SSE_PASSES_DIAG>(c, B, A) : launch_one<4, 4, SSE_MODE_PM_LDS_TABLES, 0, SSE_PASSES_DIAG>(c, B, A);
+            }
+            return launch_k<4, 4, SSE_MODE_PM_GLOBAL_TABLES>(c, B, A);
+        } else return hipErrorInvalidValue;
+    }
     if (c.mode == SSE_MODE_GLOBAL_TABLES) { // tables in HBM: slots_per_lane 4 and 1 only
         if (c.K == 4) return launch_k<W, 4, SSE_MODE_GLOBAL_TABLES>(c, B, A);
         if (c.K == 1) return launch_k<W, 1, SSE_MODE_GLOBAL_TABLES>(c, B, A);

@@ -649,6 +649,16 @@ def test_global_tables_with_per_replica_couplings_and_generic_interactions(oracl
     oracle.batch_timesteps(reps, 25, [2.0] * R)
     assert_same(g, reps, "cubic +-J, tables in HBM")
     assert g.verify().all()
+    # the same through heat-bath sweeps with a directed loop (the +-J decode serves every pass of the launch), and the general
+    # 16-byte bond records on the same model for the A-B switch
+    g.run(10, 2.0, flags=im.FLAG_HEATBATH | im.FLAG_LOOP)
+    oracle.batch_timesteps(reps, 10, [2.0] * R, 1, im.FLAG_HEATBATH | im.FLAG_LOOP)
+    assert_same(g, reps, "cubic +-J, tables in HBM, heat-bath + loop")
+    g2 = im.QmcIsingGraph(edges, 1.0, 0.1, 64, 777, nreplicas=R, capacity=1 << 13, couplings=J, cfg_flags=im.CFG_GLOBAL_TABLES | im.CFG_NO_PM_DECODE)
+    g2.run(35, 2.0)
+    reps2 = [oracle.Replica(oracle.Model(g.nvars, e, list(J[r]), 1.0, 0.1), 1 << 13, 64, 777, r, None) for r in range(R)]
+    oracle.batch_timesteps(reps2, 35, [2.0] * R)
+    assert_same(g2, reps2, "cubic +-J, tables in HBM, general bond records")
     n = 7
     ints = lat.xxz_ring_interactions(n)
     # (generic models take the general bond table by construction; cluster updates on: the model is Ising-symmetric)
