@@ -422,7 +422,19 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             po.lds_bytes = (4 * (lds_fixed_words(8, D.N, D.nwords, b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u) + 64) + 7) & ~(size_t)7;
         }
         lc.W = Wo; lc.lds_bytes = po.lds_bytes;
-        dev_off.lds_ufcap = po.ufcap; dev_off.lds_words = (uint32_t)(po.lds_bytes / 4);
+        dev_off.lds_ufcap = po.ufcap;
+        dev_off.lds_flipcap = 0u;
+        if ((is_tg(b) || hbm_uf) && !(domask & SSE_DO_RVB)) {
+            // HBM union-find launch: the LDS behind the fixed regions takes the flip bits of the ids (Wo * N + transverse ops seen so
+            // far + headroom; a replica with more ids looks its flips up in HBM as before)
+            const size_t used = po.lds_bytes / 4;
+            const size_t want = ((size_t)Wo * b->dev.N + b->max_ntrans + b->max_ntrans / 16 + 384 + 31) / 32;
+            const size_t avail = b->lds_total_words > used + 16 ? b->lds_total_words - used - 16 : 0;
+            const size_t fw = want < avail ? want : avail;
+            lc.lds_bytes = (4 * (used + fw) + 7) & ~(size_t)7;
+            dev_off.lds_flipcap = (uint32_t)(32 * fw);
+        }
+        dev_off.lds_words = (uint32_t)(lc.lds_bytes / 4);
         b->last_W_off = Wo;
     };
     bool use_dev_off = false;
@@ -552,7 +564,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
                     lo.passes = SSE_PASSES_OFFDIAG;
                     const LdsPlan po = plan_lds(b, lc.W);
                     DevBatch dv = use_dev_off ? dev_off : b->dev;
-                    lo.lds_bytes = po.lds_bytes; dv.lds_ufcap = po.ufcap; dv.lds_words = (uint32_t)(po.lds_bytes / 4);
+                    lo.lds_bytes = po.lds_bytes; dv.lds_ufcap = po.ufcap; dv.lds_flipcap = 0u; dv.lds_words = (uint32_t)(po.lds_bytes / 4);
                     if (lean_now && (rest2 & SSE_DO_CLUSTER) && !(rest2 & ~(SSE_DO_CLUSTER | SSE_DO_FREE))) e = launch_lean(a2);
                     else e = launch_dev(lo, dv, a2);
                 } else if (lean_now && (rest2 & SSE_DO_CLUSTER) && !(rest2 & ~(SSE_DO_CLUSTER | SSE_DO_FREE))) {

@@ -83,6 +83,8 @@ struct DevBatch {
     const uint32_t *ham_row; // [R] or null: with per-replica couplings, the row of the bond tables a replica runs with (null: r).
                              // Tempering between different Hamiltonians: the row belongs to the temperature slot, not the configuration
     uint32_t lds_ufcap;   // ids that fit the LDS union-find arrays
+    uint32_t lds_flipcap; // HBM union-find launches: ids whose flip BITS fit in LDS behind the fixed regions (0 = none): the apply pass
+                          // then looks the two flips of every op up in LDS instead of in the parent array in HBM
     uint32_t lds_words;   // dynamic LDS words available to the workgroup
     const double *mats;   // generic interactions (Qmc, qmc_runner.rs:415-680): [Nb][16] weights indexed in | out<<2; NULL = Ising bonds
     uint32_t bond_stride; // 0, or Nb when every replica has its own bond table / cumulative weights (per-replica couplings)
@@ -1092,8 +1094,12 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
 // Apply pass of the LDS union-find path (cluster.rs:139-167): every slot's segment ids were stored by the build
 // scan, flip bits sit in the (flattened) parent table, so the slots can be rewritten in any order: plain strided
 // streaming, no ordered scan.  Input bits flip with the incoming segment, output bits with the outgoing one.
-template <int W, int K, bool CL, bool G = false, bool PM = false>
+template <int W, int K, bool CL, bool G = false, bool PM = false, bool LF = false>
 __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Lds<W> &L, uint32_t r, uint32_t M, const UFA<G> &uf) {
+    static_assert(!LF || G, "flip bits in LDS belong to the HBM union-find path");
+    auto flip_of = [&](uint32_t id) -> uint32_t { // the flip of id: a bit in LDS (LF) or the (flattened, coin-overwritten) parent entry
+        if constexpr (LF) return (LDSW(L.o_parent, id >> 5) >> (id & 31u)) & 1u; else return uf.get(id);
+    };
     constexpr int NT = W * 64;
     const int tid = threadIdx.x;
     uint32_t *ops = B.ops + (size_t)r * B.stride;
@@ -1124,7 +1130,7 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
             const uint32_t w = wd[j];
             const bool nonempty = w != 0u;
             // segment ids of empty slots are stale: read a safe index
-            const uint32_t fa = uf.get(nonempty ? (G ? sg[j] : (sg[j] & 0xFFFFu)) : 0u), fb = uf.get(nonempty ? (G ? sh[j] : (sg[j] >> 16)) : 0u);
+            const uint32_t fa = flip_of(nonempty ? (G ? sg[j] : (sg[j] & 0xFFFFu)) : 0u), fb = flip_of(nonempty ? (G ? sh[j] : (sg[j] >> 16)) : 0u);
             bool two;
             if constexpr (CL || PM) two = nonempty & (sse_op_bond(w) < B.E);
             else two = nonempty & (second[j] != SSE_NO_VAR);
@@ -1255,6 +1261,13 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     const bool nocuts = (C == 0u);
     const uint32_t anyfrozen = LDSW(L.o_misc, MISC_ANYFROZEN);
     bool dense_done = false;
+    // HBM union-find: the flip bit of every id also goes into LDS when the launch has room for S bits behind its fixed regions
+    // (the region where the LDS union-find keeps its parents, unused on this path); the apply pass then needs no HBM lookups
+    const bool lds_flips = UF_GLOBAL && B.segs2 != nullptr && S <= B.lds_flipcap; // (uniform)
+    if (lds_flips) {
+        for (uint32_t i = tid; i < (S + 31u) / 32u; i += NT) LDSW(L.o_parent, i) = 0u;
+        __syncthreads();
+    }
     if constexpr (!UF_GLOBAL) {
         const uint32_t list_cap = ((uint32_t)W * N + 3u) / 4u * 2u;  // u16 entries in the o_cl words
         const uint32_t bits_cap = ((uint32_t)W * N + 1u) / 2u * 32u; // bits in the o_cur words
@@ -1315,6 +1328,7 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
             f = (!isfrozen && u01(o.x) < prob) ? 1u : 0u;
         }
         uf.set(i, f);
+        if (lds_flips && f) atomicOr(&LDSW(L.o_parent, i >> 5), 1u << (i & 31u));
     }
     {
         uint32_t c = myclusters;
@@ -1325,7 +1339,8 @@ __device__ __forceinline__ uint32_t cluster_pass(const DevBatch &B, const Lds<W>
     SSE_STAMP(4);
     // ---- apply (cluster.rs:139-167) ----
     if constexpr (UF_GLOBAL) {
-        if (B.segs2) cluster_apply_cached<W, K, CL, true, PM>(B, L, r, M, uf); // both ids of every slot were stored by the build scan
+        if (lds_flips) cluster_apply_cached<W, K, CL, true, PM, true>(B, L, r, M, uf);
+        else if (B.segs2) cluster_apply_cached<W, K, CL, true, PM>(B, L, r, M, uf); // both ids of every slot were stored by the build scan
         else cluster_scan<W, K, CL, true, UF_GLOBAL, TG, false, PM>(B, L, r, M, uf, C);  // (a replica that outgrew the LDS union-find before the host planned for it)
     } else cluster_apply_cached<W, K, CL, false, PM>(B, L, r, M, uf);
     SSE_STAMP(5);
