@@ -21,4 +21,7 @@ python tools/rvb_phases.py > $O/${R}_rvb_sweep.txt
 python tools/bench_tempering.py > $O/${R}_bench_tempering_64x64.json
 python tools/bench_tempering.py --window 2.0 1.05 > $O/${R}_bench_tempering_64x64_window.json
 python tools/pass_split.py > $O/${R}_pass_split.txt
+if [ -f isingmontecarlo_amd/csrc/build/exp/lib_timing.so ]; then  # diagnostic build (EXP_TU=sweep_cluster tools/experiment_build.py timing=-DSSE_PHASE_TIMING)
+  ISINGMC_HIP_LIB=isingmontecarlo_amd/csrc/build/exp/lib_timing.so python tools/attribute.py --pass cluster 0 2 16 > $O/${R}_cluster_attribution.txt
+fi
 echo "raw profiles in $O"
