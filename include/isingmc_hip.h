@@ -68,6 +68,8 @@ extern "C" {
 #define ISINGMC_CFG_NO_PM_DECODE 1024u /* large disorder batches (per-replica coupling SIGNS, uniform |J| and fields, tables in HBM) decode
                                           bonds through the per-replica 16-byte records like any other model instead of the shared compact edge
                                           table + per-replica sign bits (testing / A-B timing) */
+#define ISINGMC_CFG_RVB_FUSED 2048u /* run RVB sweeps through the fused kernel (growth and attempts in one launch, one replica per CU) even where
+                                       the two-launch form applies (csrc/sse_rvb_split.hip.h); same results (testing / measurements) */
 #define ISINGMC_CFG_FUSED_LAUNCH 2u  /* run whole timesteps inside one kernel launch instead of a diagonal-pass launch
                                         followed by an off-diagonal launch per timestep (same results, lower occupancy) */
 
@@ -283,8 +285,9 @@ int isingmc_set_steps_per_launch(isingmc_batch *b, uint64_t steps);
  * out[2]=union-find ids that fit in LDS, out[3]=state words per replica, out[4]=slots per lane,
  * out[5]=1 if the edge table is staged in LDS, out[6]=bit 0: timesteps are issued as two launches (diagonal, rest); bit 1: per-variable
  * tables live in HBM (ISINGMC_CFG_GLOBAL_TABLES path); bit 2: the diagonal-pass launch is the trimmed kernel of sse_fast.hip.h; bit 3: ... and it labels the segments for the cluster
- * update of the same timestep; bit 4: ... or hands it the dense list of occupied slots; bits 8-15: waves per replica of the
- * most recent off-diagonal launch,
+ * update of the same timestep; bit 4: ... or hands it the dense list of occupied slots; bit 5: the most recent cluster launch was the
+ * dedicated kernel; bit 6: the most recent RVB sweep ran as growth + main launches (bits 16-23: waves per replica of that main
+ * launch); bits 8-15: waves per replica of the most recent off-diagonal launch,
  * out[7]=dynamic LDS bytes of the diagonal-pass launch */
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]);
 /* Host-only: the chunk grid and op-string row stride isingmc_create derives for `capacity` slots and kernels of W (diagonal

@@ -14,7 +14,7 @@ from . import _build
 
 __all__ = ["QmcIsingGraph", "Qmc", "TemperingContainer", "NativeTemperingContainer", "IsingMcError", "load_library", "op_make", "op_fields",
            "interaction_at", "interaction_sym_under_ising",
-           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J", "CFG_GLOBAL_TABLES", "CFG_NO_FAST_DIAG", "CFG_FAST_LABEL", "CFG_COMPACT", "CFG_RVB_SERIAL_GROWTH", "CFG_NO_LEAN_CLUSTER", "CFG_NO_DEFERRED_FLIPS", "CFG_NO_PM_DECODE"]
+           "FLAG_LOOP", "FLAG_NO_CLUSTER", "FLAG_HEATBATH", "FLAG_RVB", "FLAG_PREP", "CFG_NO_LDS_TABLES", "CFG_FUSED_LAUNCH", "CFG_PER_REPLICA_J", "CFG_GLOBAL_TABLES", "CFG_NO_FAST_DIAG", "CFG_FAST_LABEL", "CFG_COMPACT", "CFG_RVB_SERIAL_GROWTH", "CFG_NO_LEAN_CLUSTER", "CFG_NO_DEFERRED_FLIPS", "CFG_NO_PM_DECODE", "CFG_RVB_FUSED"]
 
 FLAG_LOOP, FLAG_NO_CLUSTER, FLAG_HEATBATH, FLAG_RVB = 1, 2, 4, 8
 FLAG_PREP = 0x10000
@@ -27,6 +27,7 @@ CFG_RVB_SERIAL_GROWTH = 128  # RVB attempts grow their clusters one at a time (t
 CFG_COMPACT = 64  # experimental: cluster update scans the dense op list written by the trimmed diagonal kernel (same results, no net gain yet)
 CFG_NO_LEAN_CLUSTER = 256  # general cluster kernel even where the dedicated one applies (testing / A-B timing)
 CFG_NO_DEFERRED_FLIPS = 512  # the dedicated cluster kernel applies its flips itself instead of deferring them to the next diagonal launch (testing / A-B timing)
+CFG_RVB_FUSED = 2048  # RVB sweeps through the fused kernel even where the growth + main launches apply (testing / A-B timing)
 CFG_NO_PM_DECODE = 1024  # general bond records even where the +-J decode applies (testing / A-B timing)
 CFG_FUSED_LAUNCH = 2  # whole timesteps in one kernel launch (default: diagonal launch + off-diagonal launch)
 ALL = 0xFFFFFFFF
@@ -566,7 +567,7 @@ class QmcIsingGraph:
         out = (C.c_uint32 * 8)()
         self._check(self._lib.isingmc_get_launch_info(self._h, out))
         return dict(waves_per_replica=out[0], lds_bytes=out[1], lds_uf_ids=out[2], state_words=out[3],
-                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), global_tables=bool(out[6] & 2), fast_diagonal=bool(out[6] & 4), fast_label=bool(out[6] & 8), compact_list=bool(out[6] & 16), lean_cluster=bool(out[6] & 32),
+                    slots_per_lane=out[4], lds_edge_table=bool(out[5]), split_launches=bool(out[6] & 1), global_tables=bool(out[6] & 2), fast_diagonal=bool(out[6] & 4), fast_label=bool(out[6] & 8), compact_list=bool(out[6] & 16), lean_cluster=bool(out[6] & 32), rvb_split=bool(out[6] & 64), rvb_main_waves=(out[6] >> 16) & 0xFF,
                     waves_offdiag=(out[6] >> 8) & 0xFF,
                     lds_bytes_diagonal=out[7])
 

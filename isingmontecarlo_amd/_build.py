@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libisingmc_hip.so")
 STAMP = os.path.join(CSRC, "build", "build.sha256")
-SOURCES = ["isingmc_hip.hip", "sweep_fast.hip", "sweep_cluster.hip", "sweep_w1.hip", "sweep_w4.hip", "sweep_w6.hip", "sweep_w8.hip", "sweep_w16.hip"]
+SOURCES = ["isingmc_hip.hip", "sweep_fast.hip", "sweep_cluster.hip", "sweep_rvb.hip", "sweep_w1.hip", "sweep_w4.hip", "sweep_w6.hip", "sweep_w8.hip", "sweep_w16.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 LINK_LIBS = ["-ldl"]  # RCCL (parallel-tempering neighbour exchange) is dlopen()ed on first use, not linked
 if os.environ.get("SSE_MIN_WAVES"):  # experiment: force the register budget for N waves per SIMD (W = 8 kernels)

@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,6 +42,9 @@ struct isingmc_batch {
     bool last_lean = false;             // ... and the last such launch did
     bool defer = false;                 // ... leaving its flips as one byte per slot for the next (trimmed) diagonal launch to apply
     bool pending = false;               // some replicas' strings in HBM may still wait for their flip bytes (DevBatch::pend says which)
+    bool rvb_split = false;             // RVB sweeps run as a growth launch + a main launch (sse_rvb_split.hip.h) instead of the fused kernel
+    uint32_t rvb_main_W = 4;            // waves per replica of that main launch
+    bool last_rvb_split = false;        // ... and the last RVB sweep did
     std::vector<hipEvent_t> evpool;     // per-launch events of the split path (bounded, see run())
     float pass_ms[3] = {0.f, 0.f, 0.f}; // [0] diagonal-only launches, [1] all other launches of the last run, [2] of those: the RVB-sweep launches
     uint32_t pass_launches[3] = {0, 0, 0};
@@ -490,6 +494,40 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
         af.only_flagged = 1u;
         return launch_dev(lf, df, af);
     };
+    // RVB sweep: growth launch + main launch where that applies (sse_rvb_split.hip.h), else the fused kernel in geometry `lfused`
+    auto launch_rvb = [&](const LaunchCfg &lfused, const DevBatch &dfused, const SweepArgs &a) -> hipError_t {
+        const uint32_t updates = a.rvb_updates ? a.rvb_updates : (b->dev.N + 1u) / 2u;
+        b->last_rvb_split = false;
+        if (b->rvb_split && a.nsteps == 1 && updates) {
+            if (b->dev.rvb_prod_cap < updates) { // records of a sweep's attempts (grown on demand; no room -> the fused kernel)
+                if (b->dev.rvb_prod) { (void)hipStreamSynchronize(b->stream); (void)hipFree(b->dev.rvb_prod); b->dev.rvb_prod = nullptr; b->dev.rvb_prod_cap = 0; }
+                void *q = nullptr;
+                if (hipMalloc(&q, (size_t)b->dev.R * updates * rvb_split_prod_stride() * sizeof(uint32_t)) == hipSuccess) { b->dev.rvb_prod = (uint32_t *)q; b->dev.rvb_prod_cap = updates; }
+                else (void)hipGetLastError();
+            }
+            const DevBatch &D = b->dev;
+            const uint32_t ledges = b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u;
+            const size_t max_lds = b->lds_total_words * 4;
+            const size_t main_bytes = (4 * rvb_split_main_words(b->rvb_main_W, D.N, D.nwords, ledges, D.E) + 7) & ~(size_t)7;
+            if (D.rvb_prod && main_bytes <= max_lds) {
+                LaunchCfg lg = lfused;
+                size_t want = 4 * (rvb_split_grow_fixed_words(D.N, D.nwords, ledges) + (size_t)D.cap + 16 * 640 + 2);
+                if (want > max_lds) want = max_lds;
+                lg.W = 16; lg.lds_bytes = want & ~(size_t)7;
+                DevBatch dg = D;
+                dg.lds_words = (uint32_t)(lg.lds_bytes / 4);
+                hipError_t e = launch_rvb_grow(lg, dg, a);
+                if (e != hipSuccess) return e;
+                LaunchCfg lm = lfused;
+                lm.W = b->rvb_main_W; lm.lds_bytes = main_bytes;
+                DevBatch dm = D;
+                dm.lds_words = (uint32_t)(main_bytes / 4);
+                b->last_rvb_split = true;
+                return launch_rvb_main(lm, dm, a);
+            }
+        }
+        return launch_dev(lfused, dfused, a);
+    };
     HIP_TRY(b, hipEventRecord(b->ev0, b->stream));
     if (!split) {
         const uint64_t per = b->steps_per_launch ? b->steps_per_launch : nsteps;
@@ -497,7 +535,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             A.step0 = done;
             A.nsteps = (nsteps - done < per) ? nsteps - done : per;
             const bool lean_here = lean_now && A.nsteps == 1 && (A.domask & SSE_DO_CLUSTER) && !(A.domask & ~(SSE_DO_CLUSTER | SSE_DO_FREE));
-            const hipError_t e = lean_here ? launch_lean(A) : launch_dev(lc, (use_dev_off || lc.passes == SSE_PASSES_OFFDIAG) ? dev_off : b->dev, A);
+            const hipError_t e = lean_here ? launch_lean(A) : (rvb_only ? launch_rvb(lc, use_dev_off ? dev_off : b->dev, A) : launch_dev(lc, (use_dev_off || lc.passes == SSE_PASSES_OFFDIAG) ? dev_off : b->dev, A));
             if (e != hipSuccess) return fail_launch(e);
             launches++;
         }
@@ -550,7 +588,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
                 ar.domask = SSE_DO_RVB; ar.nsteps = 1; ar.step0 = done; ar.sampling_freq = 0; ar.out_u32 = nullptr;
                 LaunchCfg lr = lc;
                 lr.passes = SSE_PASSES_RVB;
-                e = launch_dev(lr, use_dev_off ? dev_off : b->dev, ar);
+                e = launch_rvb(lr, use_dev_off ? dev_off : b->dev, ar);
                 if (e != hipSuccess) return fail_launch(e);
                 launches++; b->pass_launches[1]++; b->pass_launches[2]++;
                 rest2 = rest & ~SSE_DO_RVB;
@@ -854,6 +892,9 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         const size_t want = 4 * (o_cur + 2 + rvb_fixed_words(D.N, D.E) + (size_t)D.cap);
         b->lds_bytes_rvb = (want < (size_t)max_lds ? want : (size_t)max_lds) & ~(size_t)7;
     }
+    b->rvb_split = !generic && !TG && !is_pm(b) && !b->fused_launch && !(cfg->flags & ISINGMC_CFG_RVB_FUSED);
+    if (cfg->waves_per_replica == 4 || cfg->waves_per_replica == 8 || cfg->waves_per_replica == 16) b->rvb_main_W = cfg->waves_per_replica; // an explicit geometry is honoured here too
+    if (const char *ev = getenv("ISINGMC_RVB_MAIN_W")) { const int w = atoi(ev); if (w == 4 || w == 8 || w == 16) b->rvb_main_W = (uint32_t)w; } // (tuning aid)
     size_lds(b);
     D.gamma = cfg->transverse; D.wh = 2.0 * std::fabs(cfg->longitudinal); D.hpos = cfg->longitudinal > 0.0 ? 1u : 0u;
     D.has_long = has_long ? 1u : 0u;
@@ -989,6 +1030,7 @@ void isingmc_destroy(isingmc_batch *b) {
     (void)hipSetDevice(b->device);
     pt_free(b);
     for (void *p : b->allocs) (void)hipFree(p);
+    if (b->dev.rvb_prod) (void)hipFree(b->dev.rvb_prod);
     for (hipEvent_t ev : b->evpool) (void)hipEventDestroy(ev);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -1345,7 +1387,7 @@ int isingmc_last_rvb_ms(isingmc_batch *b, float *ms, uint32_t *launches) {
 int isingmc_get_launch_info(const isingmc_batch *b, uint32_t out[8]) {
     if (!b || !out) return ISINGMC_EINVAL;
     out[0] = b->W; out[1] = (uint32_t)b->lds_bytes; out[2] = b->dev.lds_ufcap; out[3] = b->dev.nwords;
-    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u) | (b->lite ? 8u : 0u) | (b->compact ? 16u : 0u) | (b->last_lean ? 32u : 0u); out[7] = (uint32_t)diag_lds_bytes(b);
+    out[4] = b->K; out[5] = b->mode == SSE_MODE_LDS_EDGES ? 1u : 0u; out[6] = (b->fused_launch ? 0u : 1u) | (b->last_W_off << 8) | (is_tg(b) ? 2u : 0u) | (b->fast_diag ? 4u : 0u) | (b->lite ? 8u : 0u) | (b->compact ? 16u : 0u) | (b->last_lean ? 32u : 0u) | (b->last_rvb_split ? 64u : 0u) | ((b->last_rvb_split ? b->rvb_main_W : 0u) << 16); out[7] = (uint32_t)diag_lds_bytes(b);
     return ISINGMC_OK;
 }
 

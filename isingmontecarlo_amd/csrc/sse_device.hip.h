@@ -97,6 +97,8 @@ struct DevBatch {
     uint8_t *flipb;       // [R][stride] or null
     uint32_t *pend;       // [R]
     uint32_t rvb_growers; // RVB: attempts grown side by side (0 = one at a time on wave 0)
+    uint32_t *rvb_prod;   // [R][rvb_prod_cap][SSE_RVB_PROD_STRIDE] growth products of a sweep's attempts (sse_rvb_split.hip.h); null until an RVB sweep is planned
+    uint32_t rvb_prod_cap; // attempts per replica that rvb_prod holds
     uint32_t dbg_flags;   // diagnostic builds only
     unsigned long long *dbg; // [R][16] phase durations in 10-ns ticks (diagnostic builds only, -DSSE_PHASE_TIMING)
 };
@@ -1712,6 +1714,12 @@ hipError_t launch_sweep_w16(const LaunchCfg &c, const DevBatch &B, const SweepAr
 hipError_t launch_sweep_fast(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A); // sweep_fast.hip: sse_fast.hip.h, W = 4
 hipError_t launch_cluster(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);    // sweep_cluster.hip: sse_cluster.hip.h, W = 16
 size_t cluster_fixed_words(uint32_t N, uint32_t nwords, uint32_t Nb);                    // LDS words of that kernel in front of its parent table
+// sweep_rvb.hip (sse_rvb_split.hip.h): the RVB sweep as a growth launch (16 waves) and a main launch (c.W = 4, 8 or 16 waves)
+hipError_t launch_rvb_grow(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
+hipError_t launch_rvb_main(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
+size_t rvb_split_grow_fixed_words(uint32_t N, uint32_t nwords, uint32_t ledges);           // LDS words of the growth launch in front of the constant-op table
+size_t rvb_split_main_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, uint32_t E); // LDS words of the main launch
+size_t rvb_split_prod_stride();                                                          // words per attempt in DevBatch::rvb_prod
 
 template <int W, int K, int CL, int PHASE, int PASSES>
 hipError_t launch_one(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {

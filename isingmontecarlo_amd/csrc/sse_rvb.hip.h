@@ -1146,6 +1146,152 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
     LDSW(A.o_out, GO_ERR) = lerr;
 }
 
+// Phases B-D of one attempt (calculate_flip_prob, accept, mutate_graph) whose growth products — sub-variables with their starting
+// flags, toggles, windows — are the lists R points at (R0: the replica's own scratch).  Returns true when the sweep has to stop.
+template <int W, bool CL>
+__device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, const RvbLds &R0, const RvbLds &R, uint32_t r, RvbDraw g,
+                                            uint32_t nsub, uint32_t nwin, uint32_t ntog, uint32_t M, uint32_t &gr, uint32_t &nsucc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t *ops = B.ops + (size_t)r * B.stride;
+    SSE_STAMP_INIT;
+    for (uint32_t s = tid; s < nsub; s += blockDim.x) { LDSH(R0.o_v2s, LDSW(R.o_sub, s)) = (uint16_t)s; LDSW(R0.o_last, s) = 0u; }
+    __syncthreads();
+
+    // ================= phase B: calculate_flip_prob (rvb.rs:649-946) over the windows =================
+    double mult = 1.0;             // wave 0
+    uint32_t nb = 0, next_tog = 0; // wave 0
+    BSetW bw;
+    bw.o_key = R.o_bk; bw.o_wb = R.o_bwb; bw.o_wa = R.o_bwa; bw.o_ix = R.o_bix; bw.n = 0; bw.tb = 0.0; bw.ta = 0.0;
+    for (uint32_t wi = 0; wi < nwin; ++wi) {
+        const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
+        rvb_fetch<W, CL>(B, L, R, r, from, until, M, nsub, gr);
+        SSE_STAMP(8);
+        if (wave == 0 && wi == 0 && from == 0) { // set_initial_bonds (rvb.rs:617-645): the cluster's bonds to the outside, in order
+            bool ok = true;
+            for (uint32_t base = 0; base < nsub && ok; base += 64u) {
+                const uint32_t s2 = base + (uint32_t)lane;
+                uint64_t m = sse_ballot(s2 < nsub && (LDSW(R.o_sfl, s2 < nsub ? s2 : 0u) & 2u));
+                while (m && ok) {
+                    const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
+                    m &= m - 1;
+                    ok = rvb_update_bonds_w<CL, W>(B, L, R, LDSW(R.o_sub, base + k), bw, true, lane);
+                }
+            }
+            if (!ok) LDSW(R.o_ctl, RC_ERR) = 7u;
+        }
+        bool done = false;
+        for (;;) {
+            const uint32_t glen = LDSW(R.o_ctl, RC_GLEN), gp = LDSW(R.o_ctl, RC_NEXTP);
+            if (wave == 0 && !LDSW(R.o_ctl, RC_ERR)) {
+                if (rvb_replay_prob<W, CL>(B, L, R, glen, ntog, next_tog, nb, mult, bw, lane)) LDSW(R.o_ctl, RC_BROKE) = 1u;
+            }
+            __syncthreads(); // the lists are free again; everybody learns whether the product is already zero
+            SSE_STAMP(10);
+            if (LDSW(R.o_ctl, RC_BROKE) || LDSW(R.o_ctl, RC_ERR)) { done = true; break; }
+            if (M == 0u || gp > (until < M ? until : M - 1)) break;
+            rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+            SSE_STAMP(9);
+        }
+        if (done) break;
+    }
+    // ================= phase C: accept (:241-246) =================
+    if (wave == 0) {
+        if (!(nb == 0 || fabs(bw.tb - bw.ta) < 2.220446049250313e-16)) mult *= powi_sq(bw.ta / bw.tb, nb);
+        const uint4 o = g.next();
+        const bool accept = (mult >= 1.0) || (u01(o.x) < mult);
+        bw.clear(lane);
+        LDSW(R.o_ctl, RC_ACCEPT) = accept ? 1u : 0u;
+        LDSW(R.o_ctl, 9) = g.k;
+        LDSW(R.o_ctl, RC_BROKE) = 0u;
+    }
+    __syncthreads();
+    SSE_STAMP(11);
+    if (LDSW(R.o_ctl, RC_ERR)) return true;
+    g.k = LDSW(R.o_ctl, 9);
+    if (LDSW(R.o_ctl, RC_ACCEPT)) {
+        // ================= phase D: mutate_graph (:294-615) =================
+        // cluster_state := starting state
+        for (uint32_t s = tid; s < nsub; s += blockDim.x) { const uint32_t f = LDSW(R.o_sfl, s) & 1u; LDSW(R.o_sfl, s) = f | (f << 1); }
+        __syncthreads();
+        BSet bs;
+        bs.o_key = R.o_bk; bs.o_wb = R.o_bwb; bs.o_wa = R.o_bwa; bs.n = 0; bs.tb = 0.0; bs.ta = 0.0;
+        uint32_t nt2 = 0;
+        for (uint32_t wi = 0; wi < nwin; ++wi) {
+            const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
+            rvb_state_at<W, CL>(B, L, R, r, from, nsub, true); // substate ^= cluster_state (:396-399, :315-318)
+            SSE_STAMP(8);
+            if (tid == 0 && wi == 0 && from == 0) {
+                if (!rvb_initial_bonds<CL, W>(B, L, R, nsub, bs, false)) LDSW(R.o_ctl, RC_ERR) = 7u;
+            }
+            uint32_t gp = from;
+            for (;;) {
+                SSE_STAMP(12);
+                rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+                SSE_STAMP(9);
+                const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
+                gp = LDSW(R.o_ctl, RC_NEXTP);
+                if (tid == 0 && !LDSW(R.o_ctl, RC_ERR)) {
+                    for (uint32_t i = 0; i < glen; ++i) {
+                        const uint32_t p = LDSW(R.o_glp, i), wd = LDSW(R.o_glw, i);
+                        const uint32_t b = sse_op_bond(wd), in = sse_op_in(wd), out = sse_op_out(wd);
+                        const Bd d = decode_bond<CL, W>(B, L, b);
+                        const uint32_t sa = v2s_get(R, d.a), sc = d.c != SSE_NO_VAR ? v2s_get(R, d.c) : 0xFFFFu;
+                        const bool at_flip = nt2 < ntog && p == LDSW(R.o_tog, nt2);
+                        if (b < B.E && bs.find(b) >= 0) {
+                            // rotate the boundary op onto a boundary bond drawn by weight (:414-432)
+                            const uint4 o = g.next();
+                            const uint32_t nbnd = LDSW(bs.o_key, bs.pick_before(u01(o.x)));
+                            const Bd nd = decode_bond<CL, W>(B, L, nbnd);
+                            const uint32_t s2 = ((LDSW(R.o_sfl, v2s_get(R, nd.a)) >> 2) & 1u) | (((LDSW(R.o_sfl, v2s_get(R, nd.c)) >> 2) & 1u) << 1);
+                            ops[p] = sse_op_make(nbnd, s2, s2);
+                            continue;
+                        }
+                        if (at_flip) {
+                            const uint32_t cs = (LDSW(R.o_sfl, sa) >> 1) & 1u;
+                            const uint32_t nin = (in & 1u) ^ cs, nout = (out & 1u) ^ (cs ^ 1u);
+                            ops[p] = sse_op_make(b, nin, nout);
+                            LDSW(R.o_sfl, sa) = ((LDSW(R.o_sfl, sa) ^ 2u) & 3u) | (nout << 2);
+                            nt2++;
+                        } else {
+                            const bool a_in = sa != 0xFFFFu && (LDSW(R.o_sfl, sa) & 2u);
+                            const bool c_in = sc != 0xFFFFu && (LDSW(R.o_sfl, sc) & 2u);
+                            if (a_in || c_in) {
+                                const uint32_t mask = d.c != SSE_NO_VAR ? 3u : 1u;
+                                const uint32_t nin = in ^ mask, nout = out ^ mask;
+                                ops[p] = sse_op_make(b, nin, nout);
+                                if (nin != nout) {
+                                    if (sa != 0xFFFFu) LDSW(R.o_sfl, sa) = (LDSW(R.o_sfl, sa) & 3u) | ((nout & 1u) << 2);
+                                    if (sc != 0xFFFFu) LDSW(R.o_sfl, sc) = (LDSW(R.o_sfl, sc) & 3u) | (((nout >> 1) & 1u) << 2);
+                                }
+                            } else if (in != out) {
+                                if (sa != 0xFFFFu) LDSW(R.o_sfl, sa) = (LDSW(R.o_sfl, sa) & 3u) | ((out & 1u) << 2);
+                                if (sc != 0xFFFFu) LDSW(R.o_sfl, sc) = (LDSW(R.o_sfl, sc) & 3u) | (((out >> 1) & 1u) << 2);
+                            } else {
+                                continue; // diagonal and untouched by the cluster (:513-514)
+                            }
+                        }
+                        bool ok = rvb_update_bonds<CL, W>(B, L, R, d.a, bs, false);
+                        if (ok && d.c != SSE_NO_VAR) ok = rvb_update_bonds<CL, W>(B, L, R, d.c, bs, false);
+                        if (!ok) { LDSW(R.o_ctl, RC_ERR) = 7u; break; }
+                    }
+                }
+                if (M == 0u || gp > (until < M ? until : M - 1)) break;
+            }
+        }
+        __syncthreads();
+        SSE_STAMP(12);
+        // p=0 state of the sub-variables that start inside the cluster (:266-274)
+        for (uint32_t s = tid; s < nsub; s += blockDim.x)
+            if (LDSW(R.o_sfl, s) & 1u) { const uint32_t v = LDSW(R.o_sub, s); atomicXor(&LDSW(L.o_state, v >> 5), 1u << (v & 31)); }
+        nsucc++;
+    }
+    __syncthreads();
+    for (uint32_t s = tid; s < nsub; s += blockDim.x) LDSH(R.o_v2s, LDSW(R.o_sub, s)) = (uint16_t)0xFFFFu;
+    __syncthreads();
+    if (LDSW(R.o_ctl, RC_ERR)) return true;
+    return false;
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int W, bool CL>
 __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L, uint32_t r, uint64_t epoch, uint32_t M, uint32_t updates,
@@ -1199,141 +1345,7 @@ __device__ __forceinline__ uint32_t rvb_pass(const DevBatch &B, const Lds<W> &L,
         g.k = LDSW(A.o_out, GO_K);
         RvbLds R = R0; // this attempt's lists
         R.o_sub = A.o_sub; R.o_sfl = A.o_sfl; R.o_tog = A.o_tog; R.o_togs = A.o_togs; R.o_wfrom = A.o_wfrom; R.o_wuntil = A.o_wuntil;
-        for (uint32_t s = tid; s < nsub; s += blockDim.x) { LDSH(R0.o_v2s, LDSW(A.o_sub, s)) = (uint16_t)s; LDSW(R0.o_last, s) = 0u; }
-        __syncthreads();
-
-        // ================= phase B: calculate_flip_prob (rvb.rs:649-946) over the windows =================
-        double mult = 1.0;             // wave 0
-        uint32_t nb = 0, next_tog = 0; // wave 0
-        BSetW bw;
-        bw.o_key = R.o_bk; bw.o_wb = R.o_bwb; bw.o_wa = R.o_bwa; bw.o_ix = R.o_bix; bw.n = 0; bw.tb = 0.0; bw.ta = 0.0;
-        for (uint32_t wi = 0; wi < nwin; ++wi) {
-            const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
-            rvb_fetch<W, CL>(B, L, R, r, from, until, M, nsub, gr);
-            SSE_STAMP(8);
-            if (wave == 0 && wi == 0 && from == 0) { // set_initial_bonds (rvb.rs:617-645): the cluster's bonds to the outside, in order
-                bool ok = true;
-                for (uint32_t base = 0; base < nsub && ok; base += 64u) {
-                    const uint32_t s2 = base + (uint32_t)lane;
-                    uint64_t m = sse_ballot(s2 < nsub && (LDSW(R.o_sfl, s2 < nsub ? s2 : 0u) & 2u));
-                    while (m && ok) {
-                        const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
-                        m &= m - 1;
-                        ok = rvb_update_bonds_w<CL, W>(B, L, R, LDSW(R.o_sub, base + k), bw, true, lane);
-                    }
-                }
-                if (!ok) LDSW(R.o_ctl, RC_ERR) = 7u;
-            }
-            bool done = false;
-            for (;;) {
-                const uint32_t glen = LDSW(R.o_ctl, RC_GLEN), gp = LDSW(R.o_ctl, RC_NEXTP);
-                if (wave == 0 && !LDSW(R.o_ctl, RC_ERR)) {
-                    if (rvb_replay_prob<W, CL>(B, L, R, glen, ntog, next_tog, nb, mult, bw, lane)) LDSW(R.o_ctl, RC_BROKE) = 1u;
-                }
-                __syncthreads(); // the lists are free again; everybody learns whether the product is already zero
-                SSE_STAMP(10);
-                if (LDSW(R.o_ctl, RC_BROKE) || LDSW(R.o_ctl, RC_ERR)) { done = true; break; }
-                if (M == 0u || gp > (until < M ? until : M - 1)) break;
-                rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
-                SSE_STAMP(9);
-            }
-            if (done) break;
-        }
-        // ================= phase C: accept (:241-246) =================
-        if (wave == 0) {
-            if (!(nb == 0 || fabs(bw.tb - bw.ta) < 2.220446049250313e-16)) mult *= powi_sq(bw.ta / bw.tb, nb);
-            const uint4 o = g.next();
-            const bool accept = (mult >= 1.0) || (u01(o.x) < mult);
-            bw.clear(lane);
-            LDSW(R.o_ctl, RC_ACCEPT) = accept ? 1u : 0u;
-            LDSW(R.o_ctl, 9) = g.k;
-            LDSW(R.o_ctl, RC_BROKE) = 0u;
-        }
-        __syncthreads();
-        SSE_STAMP(11);
-        if (LDSW(R.o_ctl, RC_ERR)) { stop = true; break; }
-        g.k = LDSW(R.o_ctl, 9);
-        if (LDSW(R.o_ctl, RC_ACCEPT)) {
-            // ================= phase D: mutate_graph (:294-615) =================
-            // cluster_state := starting state
-            for (uint32_t s = tid; s < nsub; s += blockDim.x) { const uint32_t f = LDSW(R.o_sfl, s) & 1u; LDSW(R.o_sfl, s) = f | (f << 1); }
-            __syncthreads();
-            BSet bs;
-            bs.o_key = R.o_bk; bs.o_wb = R.o_bwb; bs.o_wa = R.o_bwa; bs.n = 0; bs.tb = 0.0; bs.ta = 0.0;
-            uint32_t nt2 = 0;
-            for (uint32_t wi = 0; wi < nwin; ++wi) {
-                const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
-                rvb_state_at<W, CL>(B, L, R, r, from, nsub, true); // substate ^= cluster_state (:396-399, :315-318)
-                SSE_STAMP(8);
-                if (tid == 0 && wi == 0 && from == 0) {
-                    if (!rvb_initial_bonds<CL, W>(B, L, R, nsub, bs, false)) LDSW(R.o_ctl, RC_ERR) = 7u;
-                }
-                uint32_t gp = from;
-                for (;;) {
-                    SSE_STAMP(12);
-                    rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
-                    SSE_STAMP(9);
-                    const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
-                    gp = LDSW(R.o_ctl, RC_NEXTP);
-                    if (tid == 0 && !LDSW(R.o_ctl, RC_ERR)) {
-                        for (uint32_t i = 0; i < glen; ++i) {
-                            const uint32_t p = LDSW(R.o_glp, i), wd = LDSW(R.o_glw, i);
-                            const uint32_t b = sse_op_bond(wd), in = sse_op_in(wd), out = sse_op_out(wd);
-                            const Bd d = decode_bond<CL, W>(B, L, b);
-                            const uint32_t sa = v2s_get(R, d.a), sc = d.c != SSE_NO_VAR ? v2s_get(R, d.c) : 0xFFFFu;
-                            const bool at_flip = nt2 < ntog && p == LDSW(R.o_tog, nt2);
-                            if (b < B.E && bs.find(b) >= 0) {
-                                // rotate the boundary op onto a boundary bond drawn by weight (:414-432)
-                                const uint4 o = g.next();
-                                const uint32_t nbnd = LDSW(bs.o_key, bs.pick_before(u01(o.x)));
-                                const Bd nd = decode_bond<CL, W>(B, L, nbnd);
-                                const uint32_t s2 = ((LDSW(R.o_sfl, v2s_get(R, nd.a)) >> 2) & 1u) | (((LDSW(R.o_sfl, v2s_get(R, nd.c)) >> 2) & 1u) << 1);
-                                ops[p] = sse_op_make(nbnd, s2, s2);
-                                continue;
-                            }
-                            if (at_flip) {
-                                const uint32_t cs = (LDSW(R.o_sfl, sa) >> 1) & 1u;
-                                const uint32_t nin = (in & 1u) ^ cs, nout = (out & 1u) ^ (cs ^ 1u);
-                                ops[p] = sse_op_make(b, nin, nout);
-                                LDSW(R.o_sfl, sa) = ((LDSW(R.o_sfl, sa) ^ 2u) & 3u) | (nout << 2);
-                                nt2++;
-                            } else {
-                                const bool a_in = sa != 0xFFFFu && (LDSW(R.o_sfl, sa) & 2u);
-                                const bool c_in = sc != 0xFFFFu && (LDSW(R.o_sfl, sc) & 2u);
-                                if (a_in || c_in) {
-                                    const uint32_t mask = d.c != SSE_NO_VAR ? 3u : 1u;
-                                    const uint32_t nin = in ^ mask, nout = out ^ mask;
-                                    ops[p] = sse_op_make(b, nin, nout);
-                                    if (nin != nout) {
-                                        if (sa != 0xFFFFu) LDSW(R.o_sfl, sa) = (LDSW(R.o_sfl, sa) & 3u) | ((nout & 1u) << 2);
-                                        if (sc != 0xFFFFu) LDSW(R.o_sfl, sc) = (LDSW(R.o_sfl, sc) & 3u) | (((nout >> 1) & 1u) << 2);
-                                    }
-                                } else if (in != out) {
-                                    if (sa != 0xFFFFu) LDSW(R.o_sfl, sa) = (LDSW(R.o_sfl, sa) & 3u) | ((out & 1u) << 2);
-                                    if (sc != 0xFFFFu) LDSW(R.o_sfl, sc) = (LDSW(R.o_sfl, sc) & 3u) | (((out >> 1) & 1u) << 2);
-                                } else {
-                                    continue; // diagonal and untouched by the cluster (:513-514)
-                                }
-                            }
-                            bool ok = rvb_update_bonds<CL, W>(B, L, R, d.a, bs, false);
-                            if (ok && d.c != SSE_NO_VAR) ok = rvb_update_bonds<CL, W>(B, L, R, d.c, bs, false);
-                            if (!ok) { LDSW(R.o_ctl, RC_ERR) = 7u; break; }
-                        }
-                    }
-                    if (M == 0u || gp > (until < M ? until : M - 1)) break;
-                }
-            }
-            __syncthreads();
-            SSE_STAMP(12);
-            // p=0 state of the sub-variables that start inside the cluster (:266-274)
-            for (uint32_t s = tid; s < nsub; s += blockDim.x)
-                if (LDSW(R.o_sfl, s) & 1u) { const uint32_t v = LDSW(R.o_sub, s); atomicXor(&LDSW(L.o_state, v >> 5), 1u << (v & 31)); }
-            nsucc++;
-        }
-        __syncthreads();
-        for (uint32_t s = tid; s < nsub; s += blockDim.x) LDSH(R.o_v2s, LDSW(R.o_sub, s)) = (uint16_t)0xFFFFu;
-        __syncthreads();
-        if (LDSW(R.o_ctl, RC_ERR)) { stop = true; break; }
+        if (rvb_attempt<W, CL>(B, L, R0, R, r, g, nsub, nwin, ntog, M, gr, nsucc)) { stop = true; break; }
     } // attempts of the batch, in order
     } // batches
     __syncthreads();

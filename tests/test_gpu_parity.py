@@ -211,7 +211,8 @@ RVB_CASES = [
 ]
 
 
-@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (1, 1, 1), (4, 2, 0), (0, 0, 128)])  # 128: attempts grown one at a time
+# 128: attempts grown one at a time; 2048: the fused kernel instead of the growth + main launches (whose main launch runs with 8, 4, 4, 16 waves here)
+@pytest.mark.parametrize("waves,k,cfgf", [(8, 4, 0), (1, 1, 1), (4, 2, 0), (0, 0, 128), (16, 4, 0), (0, 0, 2048), (8, 4, 2048 | 128)])
 @pytest.mark.parametrize("name,edges,gamma,h,beta,cutoff", RVB_CASES, ids=[c[0] for c in RVB_CASES])
 def test_rvb_update_matches_oracle(oracle, name, edges, gamma, h, beta, cutoff, waves, k, cfgf):
     """RvbUpdater::rvb_update (rvb.rs:88-290): attempt by attempt identical to the oracle (ops, state, successes)."""
@@ -234,9 +235,13 @@ def test_rvb_update_matches_oracle(oracle, name, edges, gamma, h, beta, cutoff, 
             rep.flip_free_spins()
         assert_same(g, reps, f"{name} cluster it={it}")
     assert g.verify().all()
+    info = g.launch_info()
+    assert info["rvb_split"] == (not (cfgf & 2048)), info
+    if info["rvb_split"]:
+        assert info["rvb_main_waves"] == (waves if waves in (4, 8, 16) else 4), info
 
 
-@pytest.mark.parametrize("cfgf", [0, 128])
+@pytest.mark.parametrize("cfgf", [0, 128, 2048])
 def test_rvb_dense_windows(oracle, cfgf):
     """A small lattice at low temperature: most ops touch a sub-variable, so a window's first chunk overflows the gathered-op
     list (left to the smaller gather steps, which are cut at a wave boundary) and replay batches are full."""

@@ -9,7 +9,7 @@ OUT = os.path.join(CSRC, "build", "exp")
 os.makedirs(OUT, exist_ok=True)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 TU = os.environ.get("EXP_TU", "sweep_w4")  # the translation unit rebuilt with the macros (the others come from the product build)
-others = [os.path.join(CSRC, "build", f + ".o") for f in ["isingmc_hip", "sweep_fast", "sweep_cluster", "sweep_w1", "sweep_w4", "sweep_w6", "sweep_w8", "sweep_w16"] if f != TU]
+others = [os.path.join(CSRC, "build", f + ".o") for f in ["isingmc_hip", "sweep_fast", "sweep_cluster", "sweep_rvb", "sweep_w1", "sweep_w4", "sweep_w6", "sweep_w8", "sweep_w16"] if f != TU]
 procs = []
 for spec in sys.argv[1:]:
     name, _, defs = spec.partition("=")
