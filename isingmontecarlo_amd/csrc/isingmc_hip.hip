@@ -498,17 +498,18 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
     auto launch_rvb = [&](const LaunchCfg &lfused, const DevBatch &dfused, const SweepArgs &a) -> hipError_t {
         const uint32_t updates = a.rvb_updates ? a.rvb_updates : (b->dev.N + 1u) / 2u;
         b->last_rvb_split = false;
-        if (b->rvb_split && a.nsteps == 1 && updates) {
+        const size_t pstride = rvb_split_prod_stride(b->dev.Nb);
+        if (b->rvb_split && a.nsteps == 1 && updates && pstride) {
             if (b->dev.rvb_prod_cap < updates) { // records of a sweep's attempts (grown on demand; no room -> the fused kernel)
                 if (b->dev.rvb_prod) { (void)hipStreamSynchronize(b->stream); (void)hipFree(b->dev.rvb_prod); b->dev.rvb_prod = nullptr; b->dev.rvb_prod_cap = 0; }
                 void *q = nullptr;
-                if (hipMalloc(&q, (size_t)b->dev.R * updates * rvb_split_prod_stride() * sizeof(uint32_t)) == hipSuccess) { b->dev.rvb_prod = (uint32_t *)q; b->dev.rvb_prod_cap = updates; }
+                if (hipMalloc(&q, (size_t)b->dev.R * updates * pstride * sizeof(uint32_t)) == hipSuccess) { b->dev.rvb_prod = (uint32_t *)q; b->dev.rvb_prod_cap = updates; b->dev.rvb_prod_stride = (uint32_t)pstride; }
                 else (void)hipGetLastError();
             }
             const DevBatch &D = b->dev;
             const uint32_t ledges = b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u;
             const size_t max_lds = b->lds_total_words * 4;
-            const size_t main_bytes = (4 * rvb_split_main_words(b->rvb_main_W, D.N, D.nwords, ledges, D.E) + 7) & ~(size_t)7;
+            const size_t main_bytes = (4 * rvb_split_main_words(b->rvb_main_W, D.N, D.nwords, ledges, D.E, D.Nb) + 7) & ~(size_t)7;
             if (D.rvb_prod && main_bytes <= max_lds) {
                 LaunchCfg lg = lfused;
                 size_t want = 4 * (rvb_split_grow_fixed_words(D.N, D.nwords, ledges) + (size_t)D.cap + 16 * 640 + 2);

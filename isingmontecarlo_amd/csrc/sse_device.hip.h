@@ -99,6 +99,7 @@ struct DevBatch {
     uint32_t rvb_growers; // RVB: attempts grown side by side (0 = one at a time on wave 0)
     uint32_t *rvb_prod;   // [R][rvb_prod_cap][SSE_RVB_PROD_STRIDE] growth products of a sweep's attempts (sse_rvb_split.hip.h); null until an RVB sweep is planned
     uint32_t rvb_prod_cap; // attempts per replica that rvb_prod holds
+    uint32_t rvb_prod_stride; // words per attempt in rvb_prod
     uint32_t dbg_flags;   // diagnostic builds only
     unsigned long long *dbg; // [R][16] phase durations in 10-ns ticks (diagnostic builds only, -DSSE_PHASE_TIMING)
 };
@@ -1718,8 +1719,8 @@ size_t cluster_fixed_words(uint32_t N, uint32_t nwords, uint32_t Nb);           
 hipError_t launch_rvb_grow(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 hipError_t launch_rvb_main(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A);
 size_t rvb_split_grow_fixed_words(uint32_t N, uint32_t nwords, uint32_t ledges);           // LDS words of the growth launch in front of the constant-op table
-size_t rvb_split_main_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, uint32_t E); // LDS words of the main launch
-size_t rvb_split_prod_stride();                                                          // words per attempt in DevBatch::rvb_prod
+size_t rvb_split_main_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, uint32_t E, uint32_t Nb); // LDS words of the main launch
+size_t rvb_split_prod_stride(uint32_t Nb);                                                // words per attempt in DevBatch::rvb_prod; 0 = the model is too large for the two-launch form
 
 template <int W, int K, int CL, int PHASE, int PASSES>
 hipError_t launch_one(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {

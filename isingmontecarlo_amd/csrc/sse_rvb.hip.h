@@ -52,6 +52,9 @@ struct RvbLds { // word offsets into lds_raw
     uint32_t o_cps;     // [cps_cap] constant-op positions grouped by variable
     uint32_t cps_cap;
     uint32_t adj_lds;
+    uint32_t gcap;      // entries of each gathered-op list (>= one wave's share of a gather step)
+    uint32_t o_bm;      // [ceil(Nb/32)] bit per bond: it touches a sub-variable of the current attempt (two-launch form only: BM scans)
+    uint32_t o_sadj, o_adjb; // [nsub+1] ranges into [..] the edges at each sub-variable, when the attempt's record carries them (0 = bonds_for_var in HBM)
 };
 // gathered-op info word: sub-variable of the first / second leg (SSE_GI_NONE = not a sub-variable), bond kind, two-site bit
 #define SSE_GI_NONE 0x3FFu
@@ -94,6 +97,7 @@ __device__ __forceinline__ void rvb_carve(RvbLds &R, const Lds<W> &L, const DevB
     // the candidate sets of the large growth area (weights first: doubles) share the gathered-op lists: an attempt is grown
     // before its first window is fetched, and the lists of the attempt before it are done with by then
     R.o_bfw = base; R.o_bnw = base + 2 * SSE_RVB_SETCAP; R.o_bfk = base + 4 * SSE_RVB_SETCAP; R.o_bfv = base + 5 * SSE_RVB_SETCAP; R.o_bnk = base + 6 * SSE_RVB_SETCAP;
+    R.gcap = SSE_RVB_GCAP; R.o_bm = 0u; R.o_sadj = R.o_adjb = 0u;
     R.o_glp = base; base += SSE_RVB_GCAP;
     R.o_glw = base; base += SSE_RVB_GCAP;
     R.o_gli = base; base += SSE_RVB_GCAP;
@@ -111,6 +115,13 @@ __device__ __forceinline__ uint32_t adj_begin(const RvbLds &R, const DevBatch &B
 __device__ __forceinline__ uint32_t adj_at(const RvbLds &R, const DevBatch &B, uint32_t i) {
     return R.adj_lds ? (uint32_t)LDSH(R.o_adj, i) : B.adj[i];
 }
+
+// the edges at sub-variable sv (= variable v): from the attempt's record in LDS when it carries them, else from HBM
+__device__ __forceinline__ void sadj_range(const RvbLds &R, const DevBatch &B, uint32_t v, uint32_t sv, uint32_t &i0, uint32_t &i1) {
+    if (R.o_sadj) { i0 = LDSW(R.o_sadj, sv); i1 = LDSW(R.o_sadj, sv + 1u); }
+    else { i0 = adj_begin(R, B, v); i1 = adj_begin(R, B, v + 1); }
+}
+__device__ __forceinline__ uint32_t sadj_at(const RvbLds &R, const DevBatch &B, uint32_t i) { return R.o_sadj ? LDSW(R.o_adjb, i) : adj_at(R, B, i); }
 
 struct RvbDraw {
     uint32_t k0, k1, replica, epoch_lo, attempt, k;
@@ -348,9 +359,10 @@ template <bool CL, int W>
 __device__ __forceinline__ bool rvb_update_bonds(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t v, BSet &bs, bool with_after) {
     const uint32_t sv = v2s_get(R, v);
     if (sv == 0xFFFFu) return true;
-    const uint32_t i1 = adj_begin(R, B, v + 1);
-    for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
-        const uint32_t b = adj_at(R, B, i);
+    uint32_t i0, i1;
+    sadj_range(R, B, v, sv, i0, i1);
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t b = sadj_at(R, B, i);
         const Bd d = decode_bond<CL, W>(B, L, b);
         const uint32_t ov = d.a == v ? d.c : d.a;
         const uint32_t so = v2s_get(R, ov);
@@ -382,9 +394,10 @@ __device__ __forceinline__ bool rvb_initial_bonds(const DevBatch &B, const Lds<W
     for (uint32_t s = 0; s < nsub; ++s) {
         if (!(LDSW(R.o_sfl, s) & 2u)) continue;
         const uint32_t v = LDSW(R.o_sub, s);
-        const uint32_t i1 = adj_begin(R, B, v + 1);
-        for (uint32_t i = adj_begin(R, B, v); i < i1; ++i) {
-            const uint32_t b = adj_at(R, B, i);
+        uint32_t i0, i1;
+        sadj_range(R, B, v, s, i0, i1);
+        for (uint32_t i = i0; i < i1; ++i) {
+            const uint32_t b = sadj_at(R, B, i);
             const Bd d = decode_bond<CL, W>(B, L, b);
             const uint32_t ov = d.a == v ? d.c : d.a;
             const uint32_t so = v2s_get(R, ov);
@@ -455,11 +468,12 @@ __device__ __forceinline__ bool rvb_update_bonds_w(const DevBatch &B, const Lds<
     const uint32_t sv = v2s_get(R, v);
     if (sv == 0xFFFFu) return true;
     const uint32_t fv = LDSW(R.o_sfl, sv);
-    const uint32_t i0 = adj_begin(R, B, v), i1 = adj_begin(R, B, v + 1);
+    uint32_t i0, i1;
+    sadj_range(R, B, v, sv, i0, i1);
     for (uint32_t base = i0; base < i1; base += 64u) {
         const uint32_t i = base + (uint32_t)lane;
         const bool in = i < i1;
-        const uint32_t b = adj_at(R, B, in ? i : i0);
+        const uint32_t b = sadj_at(R, B, in ? i : i0);
         const Bd d = decode_bond<CL, W>(B, L, b);
         const uint32_t ov = d.a == v ? d.c : d.a;
         const uint32_t so = v2s_get(R, ov);
@@ -590,16 +604,84 @@ __device__ __forceinline__ uint32_t rvb_find_constants(const DevBatch &B, const 
     return C;
 }
 
+// ---- scans through the attempt's bond map (BM) ----
+// The scans below visit every slot of a window and of the look-back span in front of it, and all but a few percent of the ops
+// they see touch no sub-variable.  With a bit per BOND (set by the growth launch for every bond of every sub-variable) the test
+// is one LDS read and a shift per slot; the decode and the variable -> sub-variable lookups are then done once per HIT, densely
+// (64 hits per wave instruction), instead of once per slot.
+__device__ __forceinline__ bool bm_hit(const RvbLds &R, uint32_t wd) {
+    const uint32_t b = wd ? sse_op_bond(wd) : 0u;
+    return (wd != 0u) & (((LDSW(R.o_bm, b >> 5) >> (b & 31u)) & 1u) != 0u);
+}
+// info word of a gathered op (sub-variables of its legs, bond kind)
+template <int W, bool CL>
+__device__ __forceinline__ uint32_t rvb_info_word(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t wd) {
+    const Bd d = decode_bond<CL, W>(B, L, wd ? sse_op_bond(wd) : 0u);
+    const bool two = d.c != SSE_NO_VAR;
+    const uint32_t sa = v2s_get(R, d.a), sc = v2s_get(R, two ? d.c : d.a);
+    const bool ma = sa != 0xFFFFu, mc = two & (sc != 0xFFFFu);
+    return (ma ? sa : SSE_GI_NONE) | ((mc ? sc : SSE_GI_NONE) << 10) | (bd_kind(d) << SSE_GI_KIND_SHIFT) | (two ? SSE_GI_TWO : 0u);
+}
+// last-op search: one op at slot p
+template <int W, bool CL>
+__device__ __forceinline__ void rvb_last_op(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t p, uint32_t wd) {
+    const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
+    const uint32_t sa = v2s_get(R, d.a);
+    if (sa != 0xFFFFu) atomicMax(&LDSW(R.o_last, sa), ((p + 1u) << 1) | (sse_op_out(wd) & 1u));
+    if (d.c != SSE_NO_VAR) {
+        const uint32_t sc = v2s_get(R, d.c);
+        if (sc != 0xFFFFu) atomicMax(&LDSW(R.o_last, sc), ((p + 1u) << 1) | ((sse_op_out(wd) >> 1) & 1u));
+    }
+}
+// last-op search over the U rows a thread holds (row j = slot lo + j*NT + tid, valid below hi) through the bond map: the wave
+// parks its hits in its own part of the (then idle) gathered-op lists and works them off densely; a wave with more hits than its
+// part holds takes them lane by lane.  lists_free = false: the lists are in use (the rare longer look-back of rvb_fetch).
+template <int W, bool CL, int U>
+__device__ __forceinline__ void rvb_last_ops_bm(const DevBatch &B, const Lds<W> &L, const RvbLds &R, const uint32_t (&wl)[U], uint32_t lo, uint32_t hi, bool lists_free) {
+    constexpr int NT = W * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint64_t hm[U];
+    uint32_t nh = 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint32_t p = lo + (uint32_t)(j * NT + tid);
+        hm[j] = sse_ballot((p < hi) & bm_hit(R, wl[j]));
+        nh += (uint32_t)popc64(hm[j]);
+    }
+    const uint32_t seg = R.gcap / (uint32_t)W, s0 = (uint32_t)wave * seg;
+    if (lists_free && nh <= seg) {
+        uint32_t run = s0;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if ((hm[j] >> lane) & 1ull) {
+                const uint32_t idx = run + popc64(hm[j] & lanemask_lt(lane));
+                LDSW(R.o_glp, idx) = lo + (uint32_t)(j * NT + tid);
+                LDSW(R.o_glw, idx) = wl[j];
+            }
+            run += (uint32_t)popc64(hm[j]);
+        }
+        SSE_WAVE_FENCE();
+        for (uint32_t base = 0; base < nh; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane;
+            if (i < nh) rvb_last_op<W, CL>(B, L, R, LDSW(R.o_glp, s0 + i), LDSW(R.o_glw, s0 + i));
+        }
+        SSE_WAVE_FENCE();
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if ((hm[j] >> lane) & 1ull) rvb_last_op<W, CL>(B, L, R, lo + (uint32_t)(j * NT + tid), wl[j]);
+    }
+}
+
 // Gather the ops of slots [gp, until] that touch a sub-variable, in p order, into the LDS list (one batch).
 // Returns through RC_GLEN / RC_NEXTP (slot to resume from, until+1 when the window is exhausted).  A step covers U*NT
 // slots, wave-major (a wave's lanes hold U*64 consecutive slots), and requests the next step's words before it works on
 // its own; a first step that alone overflows the list is cut at a wave boundary, so any list of >= U*64 entries is enough.
-template <int W, bool CL>
+template <int W, bool CL, int U = 8, bool BM = false>
 __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t gp, uint32_t until,
                                            uint32_t M, uint32_t &gr) {
     constexpr int NT = W * 64;
-    constexpr int U = 8;
-    static_assert(SSE_RVB_GCAP >= 64u * U, "the gathered-op list must hold one wave's share of a step");
+    static_assert(SSE_RVB_GCAP >= 64u * 8u, "the gathered-op list must hold one wave's share of a step (R.gcap >= 64 * U: the carve functions see to it)");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t last = until < M ? until : M - 1; // inclusive
@@ -621,12 +703,11 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const Bd d = decode_bond<CL, W>(B, L, wd[j] ? sse_op_bond(wd[j]) : 0u);
-            const bool two = d.c != SSE_NO_VAR;
-            const uint32_t sa = v2s_get(R, d.a), sc = v2s_get(R, two ? d.c : d.a);
-            const bool ma = sa != 0xFFFFu, mc = two & (sc != 0xFFFFu);
-            info[j] = (ma ? sa : SSE_GI_NONE) | ((mc ? sc : SSE_GI_NONE) << 10) | (bd_kind(d) << SSE_GI_KIND_SHIFT) | (two ? SSE_GI_TWO : 0u);
-            mm[j] = sse_ballot((wd[j] != 0u) & (ma | mc));
+            if constexpr (BM) { info[j] = 0u; mm[j] = sse_ballot(bm_hit(R, wd[j])); } // (the info words follow once the list is complete)
+            else {
+                info[j] = rvb_info_word<W, CL>(B, L, R, wd[j]);
+                mm[j] = sse_ballot((wd[j] != 0u) & (((info[j] & SSE_GI_NONE) != SSE_GI_NONE) | (((info[j] >> 10) & SSE_GI_NONE) != SSE_GI_NONE)));
+            }
             cnt += popc64(mm[j]);
         }
         const int buf = gr & 1;
@@ -639,9 +720,9 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
             const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2);
             if (w2 < wave) wbase += t;
             total += t;
-            if (fit_waves == (uint32_t)w2 && total <= SSE_RVB_GCAP) { fit_waves = (uint32_t)w2 + 1u; fit_total = total; } // longest prefix of waves that fits an empty list
+            if (fit_waves == (uint32_t)w2 && total <= R.gcap) { fit_waves = (uint32_t)w2 + 1u; fit_total = total; } // longest prefix of waves that fits an empty list
         }
-        const bool whole = glen + total <= SSE_RVB_GCAP;
+        const bool whole = glen + total <= R.gcap;
         if (!whole && glen != 0u) break; // this step opens the next batch
         if (whole || (uint32_t)wave < fit_waves) {
             uint32_t run = glen + wbase;
@@ -651,7 +732,7 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
                     const uint32_t idx = run + popc64(mm[j] & lanemask_lt(lane));
                     LDSW(R.o_glp, idx) = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
                     LDSW(R.o_glw, idx) = wd[j];
-                    LDSW(R.o_gli, idx) = info[j];
+                    if constexpr (!BM) LDSW(R.o_gli, idx) = info[j];
                 }
                 run += popc64(mm[j]);
             }
@@ -663,6 +744,8 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
         for (int j = 0; j < U; ++j) wd[j] = wn[j];
     }
     __syncthreads();
+    if constexpr (BM)
+        for (uint32_t i = tid; i < glen; i += NT) LDSW(R.o_gli, i) = rvb_info_word<W, CL>(B, L, R, LDSW(R.o_glw, i));
     if (tid == 0) { LDSW(R.o_ctl, RC_GLEN) = glen; LDSW(R.o_ctl, RC_NEXTP) = (M == 0u || next > last) ? last + 1 : next; }
     __syncthreads();
 }
@@ -672,11 +755,10 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
 // look-back chunk and the first window chunk are requested together, then one barrier publishes both.  o_last must be all
 // zero on entry and is left all zero.  RC_GLEN / RC_NEXTP as rvb_gather (a first chunk that overflows the list is left to
 // rvb_gather's smaller steps: RC_GLEN 0, RC_NEXTP = from).
-template <int W, bool CL>
+template <int W, bool CL, int UL = 4, int UG = 8, bool BM = false>
 __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t from, uint32_t until,
                                           uint32_t M, uint32_t nsub, uint32_t &gr) {
     constexpr int NT = W * 64;
-    constexpr int UL = 4, UG = 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t last = until < M ? until : M - 1; // inclusive
@@ -687,30 +769,22 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
     for (int j = 0; j < UL; ++j) { const uint32_t p = lo_b + (uint32_t)(j * NT + tid); wl[j] = p < from ? ops[p] : 0u; }
 #pragma unroll
     for (int j = 0; j < UG; ++j) { const uint32_t p = from + (uint32_t)(wave * 64 * UG + j * 64 + lane); wg[j] = (M != 0u && p <= last) ? ops[p] : 0u; }
+    if constexpr (BM) rvb_last_ops_bm<W, CL, UL>(B, L, R, wl, lo_b, from, true);
+    else {
 #pragma unroll
-    for (int j = 0; j < UL; ++j) {
-        if (wl[j]) {
-            const uint32_t p = lo_b + (uint32_t)(j * NT + tid);
-            const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wl[j]));
-            const uint32_t sa = v2s_get(R, d.a);
-            if (sa != 0xFFFFu) atomicMax(&LDSW(R.o_last, sa), ((p + 1u) << 1) | (sse_op_out(wl[j]) & 1u));
-            if (d.c != SSE_NO_VAR) {
-                const uint32_t sc = v2s_get(R, d.c);
-                if (sc != 0xFFFFu) atomicMax(&LDSW(R.o_last, sc), ((p + 1u) << 1) | ((sse_op_out(wl[j]) >> 1) & 1u));
-            }
-        }
+        for (int j = 0; j < UL; ++j)
+            if (wl[j]) rvb_last_op<W, CL>(B, L, R, lo_b + (uint32_t)(j * NT + tid), wl[j]);
     }
     uint32_t info[UG];
     uint64_t mm[UG];
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < UG; ++j) {
-        const Bd d = decode_bond<CL, W>(B, L, wg[j] ? sse_op_bond(wg[j]) : 0u);
-        const bool two = d.c != SSE_NO_VAR;
-        const uint32_t sa = v2s_get(R, d.a), sc = v2s_get(R, two ? d.c : d.a);
-        const bool ma = sa != 0xFFFFu, mc = two & (sc != 0xFFFFu);
-        info[j] = (ma ? sa : SSE_GI_NONE) | ((mc ? sc : SSE_GI_NONE) << 10) | (bd_kind(d) << SSE_GI_KIND_SHIFT) | (two ? SSE_GI_TWO : 0u);
-        mm[j] = sse_ballot((wg[j] != 0u) & (ma | mc));
+        if constexpr (BM) { info[j] = 0u; mm[j] = sse_ballot(bm_hit(R, wg[j])); } // (the info words follow once the list is complete)
+        else {
+            info[j] = rvb_info_word<W, CL>(B, L, R, wg[j]);
+            mm[j] = sse_ballot((wg[j] != 0u) & (((info[j] & SSE_GI_NONE) != SSE_GI_NONE) | (((info[j] >> 10) & SSE_GI_NONE) != SSE_GI_NONE)));
+        }
         cnt += popc64(mm[j]);
     }
     const int buf = gr & 1;
@@ -721,7 +795,7 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
     uint32_t wbase = 0, total = 0;
 #pragma unroll
     for (int w2 = 0; w2 < W; ++w2) { const uint32_t t = (uint32_t)LDSI(L.o_tot, buf * W + w2); if (w2 < wave) wbase += t; total += t; }
-    const bool fits = total <= SSE_RVB_GCAP;
+    const bool fits = total <= R.gcap;
     if (fits) {
         uint32_t run = wbase;
 #pragma unroll
@@ -730,7 +804,7 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
                 const uint32_t idx = run + popc64(mm[j] & lanemask_lt(lane));
                 LDSW(R.o_glp, idx) = from + (uint32_t)(wave * 64 * UG + j * 64 + lane);
                 LDSW(R.o_glw, idx) = wg[j];
-                LDSW(R.o_gli, idx) = info[j];
+                if constexpr (!BM) LDSW(R.o_gli, idx) = info[j];
             }
             run += popc64(mm[j]);
         }
@@ -746,6 +820,8 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
         LDSW(R.o_ctl, RC_NEXTP) = M == 0u ? last + 1 : (!fits ? from : (next > last ? last + 1 : next));
     }
     __syncthreads();
+    if constexpr (BM)
+        if (fits) for (uint32_t i = tid; i < total; i += NT) LDSW(R.o_gli, i) = rvb_info_word<W, CL>(B, L, R, LDSW(R.o_glw, i)); // (published by the barrier at the end)
     SSE_STAMP(1);
     uint32_t hi = lo_b;
     while (LDSW(R.o_ctl, RC_SKIP)) { // (rare) the chunks before, one barrier round each, as rvb_state_at
@@ -753,19 +829,14 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
         if (tid == 0) LDSW(R.o_ctl, RC_SKIP) = 0u;
         const uint32_t span = (uint32_t)(UL * NT);
         const uint32_t lo = hi > span ? hi - span : 0u;
+        uint32_t wx[UL];
 #pragma unroll
-        for (int j = 0; j < UL; ++j) {
-            const uint32_t p = lo + (uint32_t)(j * NT + tid);
-            const uint32_t wd = p < hi ? ops[p] : 0u;
-            if (wd) {
-                const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
-                const uint32_t sa = v2s_get(R, d.a);
-                if (sa != 0xFFFFu) atomicMax(&LDSW(R.o_last, sa), ((p + 1u) << 1) | (sse_op_out(wd) & 1u));
-                if (d.c != SSE_NO_VAR) {
-                    const uint32_t sc = v2s_get(R, d.c);
-                    if (sc != 0xFFFFu) atomicMax(&LDSW(R.o_last, sc), ((p + 1u) << 1) | ((sse_op_out(wd) >> 1) & 1u));
-                }
-            }
+        for (int j = 0; j < UL; ++j) { const uint32_t p = lo + (uint32_t)(j * NT + tid); wx[j] = p < hi ? ops[p] : 0u; }
+        if constexpr (BM) rvb_last_ops_bm<W, CL, UL>(B, L, R, wx, lo, hi, false);
+        else {
+#pragma unroll
+            for (int j = 0; j < UL; ++j)
+                if (wx[j]) rvb_last_op<W, CL>(B, L, R, lo + (uint32_t)(j * NT + tid), wx[j]);
         }
         __syncthreads();
         hi = lo;
@@ -863,11 +934,10 @@ __device__ __forceinline__ bool rvb_replay_prob(const DevBatch &B, const Lds<W> 
 
 // get_propagated_substate_with_hint (fast_ops.rs:1027-1172): the spin of every sub-variable just before slot `from`
 // = the output bit of its last op in [0, from), else the p=0 state.  Cooperative backward search.
-template <int W, bool CL>
+template <int W, bool CL, int U = 4, bool BM = false>
 __device__ __forceinline__ void rvb_state_at(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t from, uint32_t nsub,
                                              bool flip_by_cluster) {
     constexpr int NT = W * 64;
-    constexpr int U = 4;
     const int tid = threadIdx.x;
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
     for (uint32_t s = tid; s < nsub; s += NT) LDSW(R.o_last, s) = 0u;
@@ -877,21 +947,14 @@ __device__ __forceinline__ void rvb_state_at(const DevBatch &B, const Lds<W> &L,
     while (hi > 0) {
         const uint32_t span = (uint32_t)(U * NT);
         const uint32_t lo = hi > span ? hi - span : 0u;
+        uint32_t wx[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const uint32_t p = lo + (uint32_t)(j * NT + tid);
-            if (p < hi) {
-                const uint32_t wd = ops[p];
-                if (wd) {
-                    const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
-                    const uint32_t sa = v2s_get(R, d.a);
-                    if (sa != 0xFFFFu) atomicMax(&LDSW(R.o_last, sa), ((p + 1u) << 1) | (sse_op_out(wd) & 1u));
-                    if (d.c != SSE_NO_VAR) {
-                        const uint32_t sc = v2s_get(R, d.c);
-                        if (sc != 0xFFFFu) atomicMax(&LDSW(R.o_last, sc), ((p + 1u) << 1) | ((sse_op_out(wd) >> 1) & 1u));
-                    }
-                }
-            }
+        for (int j = 0; j < U; ++j) { const uint32_t p = lo + (uint32_t)(j * NT + tid); wx[j] = p < hi ? ops[p] : 0u; }
+        if constexpr (BM) rvb_last_ops_bm<W, CL, U>(B, L, R, wx, lo, hi, true); // (the gathered-op lists are idle: the gathers of this window come after)
+        else {
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (wx[j]) rvb_last_op<W, CL>(B, L, R, lo + (uint32_t)(j * NT + tid), wx[j]);
         }
         __syncthreads();
         // all found?
@@ -1148,9 +1211,12 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
 
 // Phases B-D of one attempt (calculate_flip_prob, accept, mutate_graph) whose growth products — sub-variables with their starting
 // flags, toggles, windows — are the lists R points at (R0: the replica's own scratch).  Returns true when the sweep has to stop.
-template <int W, bool CL>
+// BIG: scan steps of >= 4096 slots whatever the wave count (the main launch of the two-launch form, whose lists hold 64 * UG ops)
+template <int W, bool CL, bool BIG = false>
 __device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, const RvbLds &R0, const RvbLds &R, uint32_t r, RvbDraw g,
                                             uint32_t nsub, uint32_t nwin, uint32_t ntog, uint32_t M, uint32_t &gr, uint32_t &nsucc) {
+    constexpr int UG = BIG ? (W <= 4 ? 12 : 8) : 8, UL = BIG ? (W <= 4 ? 16 : (W <= 8 ? 8 : 4)) : 4; // (the lists of the main launch hold 64 * UG ops)
+    constexpr bool BM = BIG; // ... and its records carry the bond map
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *ops = B.ops + (size_t)r * B.stride;
     SSE_STAMP_INIT;
@@ -1164,7 +1230,7 @@ __device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, 
     bw.o_key = R.o_bk; bw.o_wb = R.o_bwb; bw.o_wa = R.o_bwa; bw.o_ix = R.o_bix; bw.n = 0; bw.tb = 0.0; bw.ta = 0.0;
     for (uint32_t wi = 0; wi < nwin; ++wi) {
         const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
-        rvb_fetch<W, CL>(B, L, R, r, from, until, M, nsub, gr);
+        rvb_fetch<W, CL, UL, UG, BM>(B, L, R, r, from, until, M, nsub, gr);
         SSE_STAMP(8);
         if (wave == 0 && wi == 0 && from == 0) { // set_initial_bonds (rvb.rs:617-645): the cluster's bonds to the outside, in order
             bool ok = true;
@@ -1189,7 +1255,7 @@ __device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, 
             SSE_STAMP(10);
             if (LDSW(R.o_ctl, RC_BROKE) || LDSW(R.o_ctl, RC_ERR)) { done = true; break; }
             if (M == 0u || gp > (until < M ? until : M - 1)) break;
-            rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+            rvb_gather<W, CL, UG, BM>(B, L, R, r, gp, until, M, gr);
             SSE_STAMP(9);
         }
         if (done) break;
@@ -1218,7 +1284,7 @@ __device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, 
         uint32_t nt2 = 0;
         for (uint32_t wi = 0; wi < nwin; ++wi) {
             const uint32_t from = LDSW(R.o_wfrom, wi), until = LDSW(R.o_wuntil, wi);
-            rvb_state_at<W, CL>(B, L, R, r, from, nsub, true); // substate ^= cluster_state (:396-399, :315-318)
+            rvb_state_at<W, CL, UL, BM>(B, L, R, r, from, nsub, true); // substate ^= cluster_state (:396-399, :315-318)
             SSE_STAMP(8);
             if (tid == 0 && wi == 0 && from == 0) {
                 if (!rvb_initial_bonds<CL, W>(B, L, R, nsub, bs, false)) LDSW(R.o_ctl, RC_ERR) = 7u;
@@ -1226,7 +1292,7 @@ __device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, 
             uint32_t gp = from;
             for (;;) {
                 SSE_STAMP(12);
-                rvb_gather<W, CL>(B, L, R, r, gp, until, M, gr);
+                rvb_gather<W, CL, UG, BM>(B, L, R, r, gp, until, M, gr);
                 SSE_STAMP(9);
                 const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
                 gp = LDSW(R.o_ctl, RC_NEXTP);

@@ -19,8 +19,8 @@ static hipError_t launch_main_one(const LaunchCfg &c, const DevBatch &B, const S
 size_t rvb_split_grow_fixed_words(uint32_t N, uint32_t nwords, uint32_t ledges) {
     return (size_t)2 * nwords + (N + 3) / 4 + 4 * 16 + 16 + 2 * SSE_MAX_CHUNKS + ledges + rvb_grow_fixed_words(N); // Lds<16>::carve up to o_cur, then rvb_carve_grow
 }
-size_t rvb_split_main_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, uint32_t E) { return rvb_main_words(W, N, nwords, ledges, E); }
-size_t rvb_split_prod_stride() { return SSE_RVB_PROD_STRIDE; }
+size_t rvb_split_main_words(uint32_t W, uint32_t N, uint32_t nwords, uint32_t ledges, uint32_t E, uint32_t Nb) { return rvb_main_words(W, N, nwords, ledges, E, Nb); }
+size_t rvb_split_prod_stride(uint32_t Nb) { return rvb_bm_words(Nb) <= SSE_RVB_BM_MAX ? SSE_RVB_PROD_STRIDE + rvb_bm_words(Nb) : 0u; }
 hipError_t launch_rvb_grow(const LaunchCfg &c, const DevBatch &B, const SweepArgs &A) {
     if (!B.rvb_prod) return hipErrorInvalidValue;
     if (c.mode == SSE_MODE_LDS_EDGES) return launch_grow_one<true>(c, B, A);
