@@ -60,7 +60,7 @@ struct RvbLds { // word offsets into lds_raw
 #define SSE_GI_NONE 0x3FFu
 #define SSE_GI_KIND_SHIFT 20
 #define SSE_GI_TWO (1u << 22)
-enum { RC_NSUB = 0, RC_NWIN = 1, RC_ACCEPT = 2, RC_GLEN = 3, RC_NEXTP = 4, RC_ERR = 5, RC_NZERO = 6, RC_SKIP = 7, RC_BROKE = 10 };
+enum { RC_NSUB = 0, RC_NWIN = 1, RC_ACCEPT = 2, RC_GLEN = 3, RC_NEXTP = 4, RC_ERR = 5, RC_NZERO = 6, RC_SKIP = 7, RC_BROKE = 10, RC_NEXTA = 11 };
 
 __device__ __forceinline__ double &ldsd(uint32_t off, uint32_t i) { return reinterpret_cast<double *>(lds_raw)[(off >> 1) + i]; }
 
@@ -1009,6 +1009,24 @@ __device__ __forceinline__ GrowArea grow_area_small(uint32_t base) { // base eve
     A.o_tmp = A.o_bfw; // (the candidate weights are dead once the cluster has its members: their room serves the sort)
     A.o_wfrom = base; base += A.cap_win;
     A.o_wuntil = base; base += A.cap_win;
+    A.o_out = base;
+    return A;
+}
+#define SSE_RVB_LARGE_WORDS (7u * SSE_RVB_SETCAP + 6u * SSE_RVB_MAXCL + 3u * SSE_RVB_MAXSUB + 2u * SSE_RVB_MAXWIN + 8u)
+__device__ __forceinline__ GrowArea grow_area_large_at(uint32_t base) { // base even (doubles first); SSE_RVB_LARGE_WORDS words
+    GrowArea A;
+    A.cap_set = SSE_RVB_SETCAP; A.cap_cl = SSE_RVB_MAXCL; A.cap_sub = SSE_RVB_MAXSUB; A.cap_win = SSE_RVB_MAXWIN;
+    A.o_bfw = base; A.o_bnw = base + 2 * SSE_RVB_SETCAP; A.o_bfk = base + 4 * SSE_RVB_SETCAP; A.o_bfv = base + 5 * SSE_RVB_SETCAP; A.o_bnk = base + 6 * SSE_RVB_SETCAP;
+    base += 7 * SSE_RVB_SETCAP;
+    A.o_clv = base; base += SSE_RVB_MAXCL;
+    A.o_clf = base; base += SSE_RVB_MAXCL;
+    A.o_tog = base; base += 2 * SSE_RVB_MAXCL;
+    A.o_togs = base; base += 2 * SSE_RVB_MAXCL;
+    A.o_sub = base; base += SSE_RVB_MAXSUB;
+    A.o_sfl = base; base += SSE_RVB_MAXSUB;
+    A.o_tmp = base; base += SSE_RVB_MAXSUB;
+    A.o_wfrom = base; base += SSE_RVB_MAXWIN;
+    A.o_wuntil = base; base += SSE_RVB_MAXWIN;
     A.o_out = base;
     return A;
 }

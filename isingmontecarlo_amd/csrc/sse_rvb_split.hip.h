@@ -176,6 +176,7 @@ __global__ __launch_bounds__(1024, 4) void rvb_grow_kernel(DevBatch B, SweepArgs
         for (uint32_t i = tid; i < B.E; i += NT) LDSW(L.o_edges, i) = B.edges_compact[i];
     RvbLds R;
     rvb_carve_grow<W>(R, L, B);
+    if (tid == 0) LDSW(R.o_ctl, RC_NEXTA) = 0u;
     __syncthreads();
     const uint32_t M = B.cutoff[r];
     const uint64_t epoch = B.epoch[r];
@@ -192,9 +193,13 @@ __global__ __launch_bounds__(1024, 4) void rvb_grow_kernel(DevBatch B, SweepArgs
     if (P > B.rvb_growers) P = B.rvb_growers;
     RvbDraw g;
     g.k0 = B.seed_lo; g.k1 = B.seed_hi; g.replica = B.rid ? B.rid[r] : B.replica_offset + r; g.epoch_lo = (uint32_t)epoch;
-    if ((uint32_t)wave < P) {
+    if ((uint32_t)wave < P) { // a wave takes the next attempt nobody has taken yet (the growths differ in length by an order of magnitude)
         const GrowArea As = grow_area_small(slots0 + (uint32_t)wave * SSE_RVB_SLOT_WORDS);
-        for (uint32_t a = (uint32_t)wave; a < updates; a += P) {
+        for (;;) {
+            uint32_t a = 0;
+            if (lane == 0) a = atomicAdd(&LDSW(R.o_ctl, RC_NEXTA), 1u);
+            a = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+            if (a >= updates) break;
             g.attempt = a; g.k = 0;
             rvb_grow<W, CL, true>(B, L, R, As, g, C, nzero, M, lane);
             SSE_WAVE_FENCE();
@@ -205,9 +210,19 @@ __global__ __launch_bounds__(1024, 4) void rvb_grow_kernel(DevBatch B, SweepArgs
     __threadfence_block();
     __syncthreads();
     SSE_STAMP(7);
-    if (wave == 0) { // clusters that outgrew a small area (or all of them when there is no room for small areas): the large one, one at a time
-        const GrowArea big = grow_area_large(R);
-        for (uint32_t base = 0; base < updates; base += 64u) {
+    // clusters that outgrew a small area (or all of them when there is no room for small areas): large areas — the fixed one and as
+    // many as the room of the small ones, now idle, holds — one wave each
+    if (tid == 0) LDSW(R.o_ctl, RC_NEXTA) = 0u;
+    __syncthreads();
+    uint32_t NL = 1u + (P * SSE_RVB_SLOT_WORDS) / SSE_RVB_LARGE_WORDS;
+    if (NL > (uint32_t)W) NL = (uint32_t)W;
+    if ((uint32_t)wave < NL) {
+        const GrowArea big = wave == 0 ? grow_area_large(R) : grow_area_large_at(slots0 + ((uint32_t)wave - 1u) * SSE_RVB_LARGE_WORDS);
+        for (;;) { // the next group of 64 attempts nobody has looked at yet
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&LDSW(R.o_ctl, RC_NEXTA), 64u);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= updates) break;
             const uint32_t a = base + (uint32_t)lane;
             uint64_t m = sse_ballot(a < updates && (P == 0u || prod[(size_t)a * B.rvb_prod_stride + GO_ERR] == SSE_RVB_REGROW));
             while (m) {
