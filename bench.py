@@ -258,9 +258,14 @@ def main():
             rest_name = "sse::cluster_kernel<K,HAS_LONG,0> (cluster + free spins + sampling; + sse::sweep_kernel<4,K,1,0,2> for flagged replicas)"
         else:
             rest_name = "sse::sweep_kernel<W,K,MODE,0,PASSES=2> (cluster + free spins + sampling)"
+        # the RVB sweep is two launches where that applies (growth of all attempts, then the attempts in order); the library counts
+        # and times the pair as one launch of this pass
+        info_now = g.launch_info() if args.rvb else {}
+        rvb_name = (f"sse::rvb_grow_kernel<CL> + sse::rvb_main_kernel<{info_now.get('rvb_main_waves')},CL> (RVB sweep)" if info_now.get("rvb_split")
+                    else "sse::sweep_kernel<16,K,MODE,0,PASSES=3> (RVB sweep, fused kernel)")
         for name, bps, ms, nl in ((diag_name, BYTES_PER_SLOT_DIAG, ms_diag, l_diag),
                                   # RVB sweep: find_constants reads the op-string twice (count + fill); window traffic not counted
-                                  ("sse::sweep_kernel<16,K,MODE,0,PASSES=3> (RVB sweep)", 8.0, ms_rvb, l_rvb),
+                                  (rvb_name, 8.0, ms_rvb, l_rvb),
                                   (rest_name, BYTES_PER_SLOT_CLUSTER, ms_rest, l_rest)):
             if nl == 0:
                 continue

@@ -28,6 +28,12 @@ namespace sse {
 #define SSE_RVB_BONDCAP 288u   // boundary bonds tracked at once
 #define SSE_RVB_GCAP 512u      // gathered ops per batch (any size >= one wave's share of a gather step works)
 #define SSE_RVB_MAXWIN 80u     // time windows of one attempt
+#ifndef SSE_RVB_UL4
+#define SSE_RVB_UL4 6  // main launch of the two-launch form with 4 waves: slots per lane of a look-back step ...
+#endif
+#ifndef SSE_RVB_UG4
+#define SSE_RVB_UG4 14 // ... and of a window step (its gathered-op lists hold 64 * UG ops)
+#endif
 
 struct RvbLds { // word offsets into lds_raw
     uint32_t o_vstart;  // [N+1]
@@ -677,21 +683,27 @@ __device__ __forceinline__ void rvb_last_ops_bm(const DevBatch &B, const Lds<W> 
 // Returns through RC_GLEN / RC_NEXTP (slot to resume from, until+1 when the window is exhausted).  A step covers U*NT
 // slots, wave-major (a wave's lanes hold U*64 consecutive slots), and requests the next step's words before it works on
 // its own; a first step that alone overflows the list is cut at a wave boundary, so any list of >= U*64 entries is enough.
+// the words of a gather's first step (requested early by the caller where it has something else to do meanwhile)
+template <int W, int U>
+__device__ __forceinline__ void rvb_gather_rows(const DevBatch &B, uint32_t r, uint32_t gp, uint32_t until, uint32_t M, uint32_t (&wd)[U]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t *ops = B.ops + (size_t)r * B.stride;
+    const uint32_t last = until < M ? until : M - 1; // inclusive
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint32_t p = gp + (uint32_t)(wave * 64 * U + j * 64 + lane);
+        wd[j] = (M != 0u && p <= last) ? ops[p] : 0u;
+    }
+}
 template <int W, bool CL, int U = 8, bool BM = false>
 __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t gp, uint32_t until,
-                                           uint32_t M, uint32_t &gr) {
+                                           uint32_t M, uint32_t &gr, uint32_t (&wd)[U]) {
     constexpr int NT = W * 64;
     static_assert(SSE_RVB_GCAP >= 64u * 8u, "the gathered-op list must hold one wave's share of a step (R.gcap >= 64 * U: the carve functions see to it)");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t last = until < M ? until : M - 1; // inclusive
     uint32_t glen = 0, next = gp;
-    uint32_t wd[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-        const uint32_t p = next + (uint32_t)(wave * 64 * U + j * 64 + lane);
-        wd[j] = (M != 0u && p <= last) ? ops[p] : 0u;
-    }
     while (M != 0u && next <= last) {
         uint32_t wn[U], info[U];
         uint64_t mm[U];
@@ -1233,7 +1245,7 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
 template <int W, bool CL, bool BIG = false>
 __device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, const RvbLds &R0, const RvbLds &R, uint32_t r, RvbDraw g,
                                             uint32_t nsub, uint32_t nwin, uint32_t ntog, uint32_t M, uint32_t &gr, uint32_t &nsucc) {
-    constexpr int UG = BIG ? (W <= 4 ? 12 : 8) : 8, UL = BIG ? (W <= 4 ? 16 : (W <= 8 ? 8 : 4)) : 4; // (the lists of the main launch hold 64 * UG ops)
+    constexpr int UG = BIG ? (W <= 4 ? SSE_RVB_UG4 : 8) : 8, UL = BIG ? (W <= 4 ? SSE_RVB_UL4 : (W <= 8 ? 8 : 4)) : 4; // (the lists of the main launch hold 64 * UG ops)
     constexpr bool BM = BIG; // ... and its records carry the bond map
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *ops = B.ops + (size_t)r * B.stride;
@@ -1266,14 +1278,18 @@ __device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, 
         bool done = false;
         for (;;) {
             const uint32_t glen = LDSW(R.o_ctl, RC_GLEN), gp = LDSW(R.o_ctl, RC_NEXTP);
+            const bool more = !(M == 0u || gp > (until < M ? until : M - 1));
+            uint32_t wrow[UG];
+            if (BIG && more) rvb_gather_rows<W, UG>(B, r, gp, until, M, wrow); // on their way while wave 0 replays this batch
             if (wave == 0 && !LDSW(R.o_ctl, RC_ERR)) {
                 if (rvb_replay_prob<W, CL>(B, L, R, glen, ntog, next_tog, nb, mult, bw, lane)) LDSW(R.o_ctl, RC_BROKE) = 1u;
             }
             __syncthreads(); // the lists are free again; everybody learns whether the product is already zero
             SSE_STAMP(10);
             if (LDSW(R.o_ctl, RC_BROKE) || LDSW(R.o_ctl, RC_ERR)) { done = true; break; }
-            if (M == 0u || gp > (until < M ? until : M - 1)) break;
-            rvb_gather<W, CL, UG, BM>(B, L, R, r, gp, until, M, gr);
+            if (!more) break;
+            if (!BIG) rvb_gather_rows<W, UG>(B, r, gp, until, M, wrow);
+            rvb_gather<W, CL, UG, BM>(B, L, R, r, gp, until, M, gr, wrow);
             SSE_STAMP(9);
         }
         if (done) break;
@@ -1310,7 +1326,9 @@ __device__ __forceinline__ bool rvb_attempt(const DevBatch &B, const Lds<W> &L, 
             uint32_t gp = from;
             for (;;) {
                 SSE_STAMP(12);
-                rvb_gather<W, CL, UG, BM>(B, L, R, r, gp, until, M, gr);
+                uint32_t wrow[UG];
+                rvb_gather_rows<W, UG>(B, r, gp, until, M, wrow);
+                rvb_gather<W, CL, UG, BM>(B, L, R, r, gp, until, M, gr, wrow);
                 SSE_STAMP(9);
                 const uint32_t glen = LDSW(R.o_ctl, RC_GLEN);
                 gp = LDSW(R.o_ctl, RC_NEXTP);

@@ -33,7 +33,7 @@ static_assert(SSE_RVB_BM_MAX <= 4u * SSE_RVB_SLOT_SET, "");
 #define SSE_RVB_NOADJ 0xFFFFFFFFu
 enum { GO_NADJ = 5 };
 __host__ __device__ inline uint32_t rvb_bm_words(uint32_t Nb) { return (Nb + 31u) >> 5; }
-__host__ __device__ inline uint32_t rvb_gcap_main(uint32_t W) { return W <= 4u ? 768u : 512u; } // = 64 * UG of rvb_attempt<W, CL, true>: a wave's share of a scan step
+__host__ __device__ inline uint32_t rvb_gcap_main(uint32_t W) { return W <= 4u ? 64u * SSE_RVB_UG4 : 512u; } // = 64 * UG of rvb_attempt<W, CL, true>: a wave's share of a scan step
 // LDS words of the record region of the main launch: two fetched-ahead parts side by side, or one whole large record over both
 __host__ __device__ inline uint32_t rvb_region_words(uint32_t bmw) {
     const uint32_t two = 2u * (SSE_RVB_PROD_AHEAD + bmw), big = SSE_RVB_PROD_STRIDE + bmw;
