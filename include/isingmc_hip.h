@@ -260,6 +260,16 @@ int isingmc_pt_nccl_unique_id(isingmc_nccl_id *out);
 int isingmc_pt_attach_nccl(isingmc_batch *b, const isingmc_nccl_id *id);
 /* TemperingContainer::tempering_step (tempering_container.rs:121-149).  *nswaps += swaps whose LOWER temperature this rank owns. */
 int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps);
+/* Where the swap decisions are taken.  A rank that owns every temperature of a batch with one Hamiltonian (world == 1, no
+ * ISINGMC_CFG_PER_REPLICA_J) decides on the device by default: one small kernel per step equalises the cutoffs of each chain, draws the
+ * same Philox numbers as the host path and swaps the labels in device memory; nothing is copied to the host unless the caller asks
+ * (isingmc_pt_step with nswaps != NULL reads 8 bytes back; isingmc_pt_get_slots / get_state refresh the host mirrors).  on = 0
+ * returns to the host path (same decisions: tested).  Multi-rank layouts and different Hamiltonians per temperature decide on the host. */
+int isingmc_pt_set_device_decisions(isingmc_batch *b, int on);
+int isingmc_pt_get_device_decisions(const isingmc_batch *b, int *on);
+/* isingmc_timesteps at the temperatures of the current labels (TemperingContainer::timesteps, tempering_container.rs:100-119); with
+ * device-side decisions the per-replica betas are read from device memory, no host array is involved */
+int isingmc_pt_timesteps(isingmc_batch *b, uint64_t t, uint32_t sampling_freq, uint32_t flags);
 /* current labels of the local replicas: global slot (t * nchains + chain), its beta, and the configuration's identity */
 int isingmc_pt_get_slots(isingmc_batch *b, uint32_t *slot_of_replica, double *beta_of_replica, uint32_t *config_id_of_replica);
 

@@ -116,6 +116,9 @@ SYMBOLS = {
     "isingmc_pt_attach_nccl": (C.c_int, [_vp, _P(_NcclId)]),
     "isingmc_pt_step": (C.c_int, [_vp, _P(_u64)]),
     "isingmc_pt_get_slots": (C.c_int, [_vp, _P(_u32), _P(_f64), _P(_u32)]),
+    "isingmc_pt_set_device_decisions": (C.c_int, [_vp, C.c_int]),
+    "isingmc_pt_get_device_decisions": (C.c_int, [_vp, _P(C.c_int)]),
+    "isingmc_pt_timesteps": (C.c_int, [_vp, _u64, _u32, _u32]),
     "isingmc_pt_get_state": (C.c_int, [_vp, _P(_u64), _P(_u64)]),
     "isingmc_pt_set_state": (C.c_int, [_vp, _P(_u32), _P(_u32), _u64, _u64]),
     "isingmc_set_accumulator_rows": (C.c_int, [_vp, _u32, _P(_u32)]),

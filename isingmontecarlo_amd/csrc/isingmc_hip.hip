@@ -42,6 +42,7 @@ struct isingmc_batch {
     bool last_lean = false;             // ... and the last such launch did
     bool defer = false;                 // ... leaving its flips as one byte per slot for the next (trimmed) diagonal launch to apply
     bool pending = false;               // some replicas' strings in HBM may still wait for their flip bytes (DevBatch::pend says which)
+    const double *beta_dev = nullptr;   // isingmc_pt_timesteps: per-replica betas already on the device (used when the caller passes none)
     bool rvb_split = false;             // RVB sweeps run as a growth launch + a main launch (sse_rvb_split.hip.h) instead of the fused kernel
     uint32_t rvb_main_W = 4;            // waves per replica of that main launch
     bool last_rvb_split = false;        // ... and the last RVB sweep did
@@ -352,6 +353,8 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
             if (!(beta[r] >= 0.0) || !std::isfinite(beta[r])) { b->err = "beta must be finite and >= 0"; return ISINGMC_EINVAL; }
         HIP_TRY(b, hipMemcpyAsync(b->d_beta, beta, sizeof(double) * b->dev.R, hipMemcpyHostToDevice, b->stream));
         A.beta = b->d_beta;
+    } else if (b->beta_dev) {
+        A.beta = b->beta_dev;
     } else if (domask & SSE_DO_DIAG) {
         b->err = "beta is required for a diagonal update";
         return ISINGMC_EINVAL;
@@ -1427,6 +1430,12 @@ struct PtState {
     int (*p_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*p_init)(void **, int, isingmc_nccl_id, int) = nullptr;
     int (*p_destroy)(void *) = nullptr;
+    // decisions on the device (single rank, one Hamiltonian for all temperatures): labels, betas per replica and the swap count live
+    // in device memory; the host mirrors (slot_of) are refreshed on demand
+    bool dev_decide = false, host_stale = false;
+    uint32_t *d_slot_of = nullptr, *d_at = nullptr, *d_result = nullptr; // d_result: [0] swaps of the last step, [1] error flag
+    double *d_betas = nullptr, *d_beta_r = nullptr;
+    unsigned long long *d_total = nullptr; // total swaps since isingmc_pt_create / set_state
     uint32_t *d_items = nullptr; // [3 * nchains] accepted boundary swaps of one turn: (replica, word offset, cutoff)
     uint32_t *d_small = nullptr; // [4][nchains] staging of the boundary operator counts / cutoffs on the device (RCCL path)
     // different Hamiltonians per temperature (per-replica couplings): J rows of the neighbouring ranks' boundary slots
@@ -1443,7 +1452,8 @@ static void pt_free(isingmc_batch *b) {
     if (!b->pt) return;
     PtState *P = b->pt;
     if (P->comm && P->p_destroy) (void)P->p_destroy(P->comm);
-    for (void *q : {(void *)P->d_rid, (void *)P->d_ham_row, (void *)P->d_small, (void *)P->d_counts, (void *)P->d_pack_s, (void *)P->d_pack_r, (void *)P->d_items})
+    for (void *q : {(void *)P->d_rid, (void *)P->d_ham_row, (void *)P->d_small, (void *)P->d_counts, (void *)P->d_pack_s, (void *)P->d_pack_r, (void *)P->d_items,
+                    (void *)P->d_slot_of, (void *)P->d_at, (void *)P->d_result, (void *)P->d_betas, (void *)P->d_beta_r, (void *)P->d_total})
         if (q) (void)hipFree(q);
     delete P;
     b->pt = nullptr;
@@ -1486,6 +1496,56 @@ __global__ void pt_bond_count_kernel(DevBatch B, uint32_t *counts) {
     __syncthreads();
     const uint32_t M = B.cutoff[r];
     for (uint32_t p = threadIdx.x; p < M; p += blockDim.x) { const uint32_t w = ops[p]; if (w) atomicAdd(&c[sse_op_bond(w)], 1u); }
+}
+
+struct PtDev {
+    uint32_t *slot_of, *at, *result, *acc_row;
+    const double *betas;
+    double *beta_r;
+    unsigned long long *total;
+    uint32_t K, T, key0, key1;
+    uint64_t step;
+};
+__device__ __forceinline__ double pt_dev_powi_signed(double x, long long n) { // (the multiplication sequence of pt_powi_signed)
+    unsigned long long m = n < 0 ? (unsigned long long)(-n) : (unsigned long long)n;
+    double r = 1.0;
+    while (m) { if (m & 1ull) r *= x; x *= x; m >>= 1; }
+    return n < 0 ? 1.0 / r : r;
+}
+// One tempering step of a rank that owns all temperatures (tempering_container.rs:121-149; the decisions of isingmc_pt_step's host
+// path, same Philox counters): thread k takes chain k — equalise its cutoffs, draw the order coin, walk the two sets of pairs.
+__global__ void pt_decide_kernel(DevBatch B, PtDev P) {
+    __shared__ unsigned int s_swaps;
+    if (threadIdx.x == 0) s_swaps = 0u;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < P.K; k += blockDim.x) {
+        uint32_t maxcut = 0;
+        for (uint32_t t = 0; t < P.T; ++t) { const uint32_t c = B.cutoff[P.at[t * P.K + k]]; maxcut = c > maxcut ? c : maxcut; }
+        if (maxcut > B.cap) { P.result[1] = 1u; continue; }
+        for (uint32_t t = 0; t < P.T; ++t) B.cutoff[P.at[t * P.K + k]] = maxcut;
+        const uint32_t c3 = (SSE_TAG_PT << 24) | (uint32_t)((P.step >> 32) & 0xFFFFFFu);
+        const bool a_first = (philox4x32_10(0u, (uint32_t)P.step, k, c3, P.key0, P.key1).x >> 31) != 0u;
+        uint32_t swaps = 0;
+        for (int phase = 0; phase < 2; ++phase) {
+            const bool set_a = (phase == 0) ? a_first : !a_first;
+            for (uint32_t t = 0; t + 1 < P.T; ++t) {
+                if ((((t & 1u) == 0u) != set_a)) continue;
+                const uint32_t la = t * P.K + k, lb = la + P.K;
+                const uint32_t ra = P.at[la], rb = P.at[lb];
+                const double u = (double)philox4x32_10(1u + t, (uint32_t)P.step, k, c3, P.key0, P.key1).x * (1.0 / 4294967296.0);
+                const double p = pt_dev_powi_signed(P.betas[t] / P.betas[t + 1], (long long)B.n[rb] - (long long)B.n[ra]);
+                if (p > u) { P.slot_of[ra] = lb; P.slot_of[rb] = la; P.at[la] = rb; P.at[lb] = ra; swaps++; }
+            }
+        }
+        for (uint32_t t = 0; t < P.T; ++t) {
+            const uint32_t r = P.at[t * P.K + k];
+            P.beta_r[r] = P.betas[t];
+            if (P.acc_row) P.acc_row[r] = t * P.K + k;
+        }
+        if (swaps) atomicAdd(&s_swaps, swaps);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { P.result[0] = s_swaps; *P.total += s_swaps; }
 }
 
 static double pt_powi(double x, uint32_t n) { // x^n by squaring (the oracle uses the same multiplication sequence)
@@ -1542,6 +1602,40 @@ static int pt_exchange_small(isingmc_batch *b, int peer, const uint32_t *s, uint
 
 extern "C" {
 
+// device-side decisions: push the host's labels to the device / pull them back
+static int pt_upload_labels(isingmc_batch *b) {
+    PtState *P = b->pt;
+    const uint32_t R = b->dev.R, K = P->nchains;
+    std::vector<uint32_t> at(R);
+    std::vector<double> br(R);
+    for (uint32_t r = 0; r < R; ++r) { at[P->slot_of[r] - P->rank * R] = r; br[r] = P->betas[P->slot_of[r] / K]; }
+    const unsigned long long tot = P->total_swaps;
+    const uint32_t zero[2] = {0u, 0u};
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    HIP_TRY(b, hipMemcpy(P->d_slot_of, P->slot_of.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(P->d_at, at.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(P->d_beta_r, br.data(), 8 * (size_t)R, hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(P->d_total, &tot, 8, hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(P->d_result, zero, 8, hipMemcpyHostToDevice));
+    P->host_stale = false;
+    return ISINGMC_OK;
+}
+static int pt_sync_host(isingmc_batch *b) {
+    PtState *P = b->pt;
+    if (!P->dev_decide || !P->host_stale) return ISINGMC_OK;
+    HIP_TRY(b, hipSetDevice(b->device));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    unsigned long long tot = 0;
+    uint32_t res[2] = {0u, 0u};
+    HIP_TRY(b, hipMemcpy(P->slot_of.data(), P->d_slot_of, 4 * (size_t)b->dev.R, hipMemcpyDeviceToHost));
+    HIP_TRY(b, hipMemcpy(&tot, P->d_total, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(b, hipMemcpy(res, P->d_result, 8, hipMemcpyDeviceToHost));
+    P->total_swaps = tot;
+    P->host_stale = false;
+    if (res[1]) { b->err = "cutoff exceeds capacity"; return ISINGMC_ECAPACITY; }
+    return ISINGMC_OK;
+}
+
 int isingmc_pt_create(isingmc_batch *b, const isingmc_pt_layout *lay) {
     if (!b || !lay || lay->struct_size != sizeof(isingmc_pt_layout) || !lay->betas || lay->ntemps == 0 || lay->nchains == 0 || lay->world == 0 ||
         lay->rank >= lay->world || lay->ntemps % lay->world) { if (b) b->err = "bad tempering layout (temperatures must divide evenly over the ranks)"; return ISINGMC_EINVAL; }
@@ -1587,7 +1681,47 @@ int isingmc_pt_create(isingmc_batch *b, const isingmc_pt_layout *lay) {
             if (next < (int)P->world && P->tr.sendrecv(P->tr.ctx, next, last.data(), 8 * last.size(), P->J_next_first.data(), 8 * last.size())) { b->err = "tempering transport failed"; return ISINGMC_EINVAL; }
         }
     }
+    if (P->world == 1 && !P->hams_differ) { // every pair is interior and weighs one Hamiltonian: the decisions run on the device
+        HIP_TRY(b, hipMalloc((void **)&P->d_slot_of, 4 * (size_t)R));
+        HIP_TRY(b, hipMalloc((void **)&P->d_at, 4 * (size_t)R));
+        HIP_TRY(b, hipMalloc((void **)&P->d_result, 8));
+        HIP_TRY(b, hipMalloc((void **)&P->d_betas, 8 * (size_t)P->ntemps));
+        HIP_TRY(b, hipMalloc((void **)&P->d_beta_r, 8 * (size_t)R));
+        HIP_TRY(b, hipMalloc((void **)&P->d_total, 8));
+        HIP_TRY(b, hipMemcpy(P->d_betas, P->betas.data(), 8 * (size_t)P->ntemps, hipMemcpyHostToDevice));
+        const int rcu = pt_upload_labels(b);
+        if (rcu) return rcu;
+        P->dev_decide = true;
+    }
     return ISINGMC_OK;
+}
+int isingmc_pt_set_device_decisions(isingmc_batch *b, int on) {
+    if (!b || !b->pt) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    PtState *P = b->pt;
+    HIP_TRY(b, hipSetDevice(b->device));
+    if (on && !P->d_slot_of) { b->err = "device-side tempering decisions need a single rank and one Hamiltonian for all temperatures"; return ISINGMC_ENOTIMPL; }
+    if (!on && P->dev_decide) { const int rc = pt_sync_host(b); if (rc) return rc; P->dev_decide = false; }
+    else if (on && !P->dev_decide) { const int rc = pt_upload_labels(b); if (rc) return rc; P->dev_decide = true; }
+    return ISINGMC_OK;
+}
+int isingmc_pt_get_device_decisions(const isingmc_batch *b, int *on) {
+    if (!b || !b->pt || !on) return ISINGMC_EINVAL;
+    *on = b->pt->dev_decide ? 1 : 0;
+    return ISINGMC_OK;
+}
+// Sweeps at the temperatures of the current labels.  With device-side decisions the betas never visit the host.
+int isingmc_pt_timesteps(isingmc_batch *b, uint64_t t, uint32_t sampling_freq, uint32_t flags) {
+    if (!b || !b->pt) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    PtState *P = b->pt;
+    if (P->dev_decide) {
+        b->beta_dev = P->d_beta_r;
+        const int rc = isingmc_timesteps(b, t, nullptr, sampling_freq, flags);
+        b->beta_dev = nullptr;
+        return rc;
+    }
+    std::vector<double> br(b->dev.R);
+    for (uint32_t r = 0; r < b->dev.R; ++r) br[r] = P->betas[P->slot_of[r] / P->nchains];
+    return isingmc_timesteps(b, t, br.data(), sampling_freq, flags);
 }
 
 int isingmc_pt_nccl_unique_id(isingmc_nccl_id *out) {
@@ -1625,6 +1759,7 @@ int isingmc_pt_attach_nccl(isingmc_batch *b, const isingmc_nccl_id *id) {
 
 int isingmc_pt_get_slots(isingmc_batch *b, uint32_t *slot_of_replica, double *beta_of_replica, uint32_t *config_id_of_replica) {
     if (!b || !b->pt) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    { const int rcs = pt_sync_host(b); if (rcs) return rcs; }
     const PtState *P = b->pt;
     for (uint32_t r = 0; r < b->dev.R; ++r) {
         if (slot_of_replica) slot_of_replica[r] = P->slot_of[r];
@@ -1638,6 +1773,7 @@ int isingmc_pt_get_slots(isingmc_batch *b, uint32_t *slot_of_replica, double *be
 // the configurations' identities and the step counter; the replicas themselves go through the batch's own checkpoint.
 int isingmc_pt_get_state(isingmc_batch *b, uint64_t *step, uint64_t *total_swaps) {
     if (!b || !b->pt) { if (b) b->err = "isingmc_pt_create first"; return ISINGMC_EINVAL; }
+    { const int rcs = pt_sync_host(b); if (rcs) return rcs; }
     if (step) *step = b->pt->step;
     if (total_swaps) *total_swaps = b->pt->total_swaps;
     return ISINGMC_OK;
@@ -1659,6 +1795,7 @@ int isingmc_pt_set_state(isingmc_batch *b, const uint32_t *slot_of_replica, cons
         HIP_TRY(b, hipMemcpy(P->d_ham_row, b->ham_row_host.data(), 4 * (size_t)R, hipMemcpyHostToDevice));
     }
     P->step = step; P->total_swaps = total_swaps;
+    if (P->dev_decide) return pt_upload_labels(b);
     return ISINGMC_OK;
 }
 
@@ -1669,6 +1806,25 @@ int isingmc_pt_step(isingmc_batch *b, uint64_t *nswaps) {
     PtState *P = b->pt;
     HIP_TRY(b, hipSetDevice(b->device));
     const uint32_t R = b->dev.R, K = P->nchains, T = P->ntemps, tper = P->tper, E = b->dev.E, Nb = b->dev.Nb;
+    if (P->dev_decide) { // label swaps only: the op-strings (and any flip bytes still pending on them) are not touched
+        if (T <= 1) { P->step++; return ISINGMC_OK; }
+        PtDev D{};
+        D.slot_of = P->d_slot_of; D.at = P->d_at; D.result = P->d_result; D.betas = P->d_betas; D.beta_r = P->d_beta_r; D.total = P->d_total;
+        D.acc_row = b->acc_rows == T * K ? b->d_acc_row : nullptr; // per-slot accumulators (isingmc_set_accumulator_rows with the slots) follow the labels
+        D.K = K; D.T = T; D.key0 = (uint32_t)P->seed; D.key1 = (uint32_t)(P->seed >> 32); D.step = P->step;
+        hipLaunchKernelGGL(pt_decide_kernel, dim3(1), dim3(K < 256 ? ((K + 63) / 64) * 64 : 256), 0, b->stream, b->dev, D);
+        HIP_TRY(b, hipGetLastError());
+        P->step++;
+        P->host_stale = true;
+        if (nswaps) { // the caller wants this step's count: one small read-back
+            uint32_t res[2] = {0u, 0u};
+            HIP_TRY(b, hipStreamSynchronize(b->stream));
+            HIP_TRY(b, hipMemcpy(res, P->d_result, 8, hipMemcpyDeviceToHost));
+            if (res[1]) { b->err = "cutoff exceeds capacity"; return ISINGMC_ECAPACITY; }
+            *nswaps += res[0];
+        }
+        return ISINGMC_OK;
+    }
     { const int rcm = ensure_materialized(b); if (rcm) return rcm; }
     const uint32_t t_lo = P->rank * tper, t_hi = t_lo + tper; // my temperature block [t_lo, t_hi)
     const int prev = P->rank > 0 ? (int)P->rank - 1 : -1, next = P->rank + 1 < P->world ? (int)P->rank + 1 : -1;

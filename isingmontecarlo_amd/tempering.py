@@ -202,7 +202,29 @@ class NativeTemperingContainer:
                         transport=C.pointer(self._tr) if self.world > 1 else None)
         graph._check(graph._lib.isingmc_pt_create(graph._h, C.byref(lay)))
         self.total_swaps_local = 0
+        self._stale = True
         self._refresh()
+
+    # Labels.  With device-side decisions (single rank, one Hamiltonian: the library's default there) the labels live in device memory;
+    # these mirrors are refreshed when somebody looks at them, not after every step.
+    @property
+    def device_decisions(self):
+        on = C.c_int(0)
+        self.g._check(self.g._lib.isingmc_pt_get_device_decisions(self.g._h, C.byref(on)))
+        return bool(on.value)
+
+    def set_device_decisions(self, on):
+        self.g._check(self.g._lib.isingmc_pt_set_device_decisions(self.g._h, 1 if on else 0))
+        self._stale = True
+
+    slot_of = property(lambda self: self._mirror("_slot_of"))
+    local_betas = property(lambda self: self._mirror("_local_betas"))
+    config_of = property(lambda self: self._mirror("_config_of"))
+
+    def _mirror(self, name):
+        if self._stale:
+            self._refresh()
+        return getattr(self, name)
 
     # ---- host-staged transport over torch.distributed (CPU tensors with gloo, device tensors with nccl) ----
     def _tensor_dev(self):
@@ -253,22 +275,36 @@ class NativeTemperingContainer:
     # ---- labels ----
     def _refresh(self):
         R = self.g.nreplicas
-        self.slot_of = np.zeros(R, dtype=np.uint32)
-        self.local_betas = np.zeros(R, dtype=np.float64)
-        self.config_of = np.zeros(R, dtype=np.uint32)
-        self.g._check(self.g._lib.isingmc_pt_get_slots(self.g._h, self.slot_of.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                                         self.local_betas.ctypes.data_as(C.POINTER(C.c_double)),
-                                                         self.config_of.ctypes.data_as(C.POINTER(C.c_uint32))))
-        self.g.set_accumulator_rows(self.ntemps * self.nchains, self.slot_of)
+        self._slot_of = np.zeros(R, dtype=np.uint32)
+        self._local_betas = np.zeros(R, dtype=np.float64)
+        self._config_of = np.zeros(R, dtype=np.uint32)
+        self.g._check(self.g._lib.isingmc_pt_get_slots(self.g._h, self._slot_of.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                         self._local_betas.ctypes.data_as(C.POINTER(C.c_double)),
+                                                         self._config_of.ctypes.data_as(C.POINTER(C.c_uint32))))
+        self._stale = False
+        # accumulators per temperature slot (the decision kernel keeps the rows up to date afterwards when it runs on the device)
+        self.g.set_accumulator_rows(self.ntemps * self.nchains, self._slot_of)
 
     # ---- reference API ----
     def num_graphs(self):
         return self.ntemps * self.nchains
 
     def timesteps(self, t, sampling_freq=1):
-        self.g.run(int(t), self.local_betas, sampling_freq, self.flags)
+        if int(t) > 0:
+            self.g._check(self.g._lib.isingmc_pt_timesteps(self.g._h, int(t), int(sampling_freq), int(self.flags)))
 
-    def tempering_step(self):
+    def tempering_step(self, count_swaps=True):
+        """One tempering step; returns the swaps this rank counted (None with count_swaps=False, which spares the device-side path
+        its only read-back: get_total_swaps() still has the total)."""
+        if self.device_decisions:
+            if count_swaps:
+                sw = C.c_uint64(0)
+                self.g._check(self.g._lib.isingmc_pt_step(self.g._h, C.byref(sw)))
+            else:
+                sw = None
+                self.g._check(self.g._lib.isingmc_pt_step(self.g._h, None))
+            self._stale = True
+            return None if sw is None else int(sw.value)
         sw = C.c_uint64(0)
         self.g._check(self.g._lib.isingmc_pt_step(self.g._h, C.byref(sw)))
         self.total_swaps_local += int(sw.value)
@@ -276,6 +312,10 @@ class NativeTemperingContainer:
         return int(sw.value)
 
     def get_total_swaps(self):
+        if self.device_decisions:
+            step, sw = C.c_uint64(0), C.c_uint64(0)
+            self.g._check(self.g._lib.isingmc_pt_get_state(self.g._h, C.byref(step), C.byref(sw)))
+            return int(sw.value)
         if not self.dist:
             return self.total_swaps_local
         import torch
@@ -305,4 +345,5 @@ class NativeTemperingContainer:
         self.g._check(self.g._lib.isingmc_pt_set_state(self.g._h, so.ctypes.data_as(C.POINTER(C.c_uint32)), co.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                         int(z["step"]), int(z["swaps"])))
         self.total_swaps_local = int(z["swaps_local"])
+        self._stale = True
         self._refresh()

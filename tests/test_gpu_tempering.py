@@ -24,15 +24,25 @@ def oracle_reference(oracle):
     return reference_pt(m, BETAS, K, SEED, 4096, 16, nsteps=STEPS, sweeps_per_step=SWEEPS)
 
 
-def test_native_step_single_rank_matches_oracle(oracle):
+@pytest.mark.parametrize("where", ["device", "device, nothing read back between steps", "host"])
+def test_native_step_single_rank_matches_oracle(oracle, where):
+    """A rank that owns all temperatures takes the swap decisions in a kernel (labels, betas per replica, accumulator rows and the
+    swap count stay in device memory); the host path takes the same ones."""
     import isingmontecarlo_amd as im
     by_slot, swaps_ref = oracle_reference(oracle)
     g = im.QmcIsingGraph(lat.two_d_periodic(4), 1.0, 0.0, 16, SEED, nreplicas=len(BETAS) * K, capacity=4096)
     tc = im.NativeTemperingContainer(g, BETAS, K, SEED)
+    assert tc.device_decisions  # the default for this layout
+    if where == "host":
+        tc.set_device_decisions(False)
+    counted = 0
     for _ in range(STEPS):
         tc.timesteps(SWEEPS)
-        tc.tempering_step()
+        sw = tc.tempering_step(count_swaps=where != "device, nothing read back between steps")
+        counted += sw or 0
+    assert tc.device_decisions == (where != "host")
     assert tc.get_total_swaps() == swaps_ref and swaps_ref > 0
+    assert counted == (0 if where == "device, nothing read back between steps" else swaps_ref)
     st, n, cut = g.state_ref(), g.get_n(), g.get_cutoff()
     for r in range(g.nreplicas):
         t, k = divmod(int(tc.slot_of[r]), K)

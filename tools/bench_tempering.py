@@ -42,12 +42,12 @@ tc = NativeTemperingContainer(g, betas, a.nchains, a.seed, flags=0)
 if a.rccl and world > 1:
     tc.attach_rccl()  # (never executed on hardware so far: run tools/rccl_selfcheck.py first on a multi-GPU node)
 for _ in range(a.equilibrate):
-    tc.timesteps(1); tc.tempering_step()
+    tc.timesteps(1); tc.tempering_step(count_swaps=False)
 g.reset_accumulators()
 swaps0 = tc.get_total_swaps()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
-    tc.timesteps(1); tc.tempering_step()
+    tc.timesteps(1); tc.tempering_step(count_swaps=False)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 acc = g.accumulators().astype(np.float64)
 if rank == 0:

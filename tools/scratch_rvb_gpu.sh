@@ -1,3 +1,3 @@
 set -e
-timeout -k 10 1000 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
-timeout -k 10 120 python bench.py --rvb --steps 4 --warmup 1 --equilibrate 60 --no-cpu-baseline
+timeout -k 10 900 python -m pytest tests/test_gpu_tempering.py -x -q -m gpu 2>&1 | tail -5
+timeout -k 10 300 python tools/bench_tempering.py
