@@ -897,8 +897,12 @@ int isingmc_create(const isingmc_config *cfg, isingmc_batch **out) {
         b->lds_bytes_rvb = (want < (size_t)max_lds ? want : (size_t)max_lds) & ~(size_t)7;
     }
     b->rvb_split = !generic && !TG && !is_pm(b) && !b->fused_launch && !(cfg->flags & ISINGMC_CFG_RVB_FUSED);
+    { // waves of the RVB main launch: as many as keep about 16 waves on a CU (its LDS footprint decides how many replicas share one)
+        const size_t w4 = 4 * rvb_split_main_words(4, D.N, D.nwords, CL ? D.E : 0u, D.E, D.Nb);
+        const size_t per_cu = w4 ? (size_t)max_lds / w4 : 0;
+        b->rvb_main_W = per_cu >= 4 ? 4u : (per_cu >= 2 ? 8u : 16u);
+    }
     if (cfg->waves_per_replica == 4 || cfg->waves_per_replica == 8 || cfg->waves_per_replica == 16) b->rvb_main_W = cfg->waves_per_replica; // an explicit geometry is honoured here too
-    if (const char *ev = getenv("ISINGMC_RVB_MAIN_W")) { const int w = atoi(ev); if (w == 4 || w == 8 || w == 16) b->rvb_main_W = (uint32_t)w; } // (tuning aid)
     size_lds(b);
     D.gamma = cfg->transverse; D.wh = 2.0 * std::fabs(cfg->longitudinal); D.hpos = cfg->longitudinal > 0.0 ? 1u : 0u;
     D.has_long = has_long ? 1u : 0u;
