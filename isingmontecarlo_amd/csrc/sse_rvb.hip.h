@@ -29,10 +29,10 @@ namespace sse {
 #define SSE_RVB_GCAP 512u      // gathered ops per batch (any size >= one wave's share of a gather step works)
 #define SSE_RVB_MAXWIN 80u     // time windows of one attempt
 #ifndef SSE_RVB_UL4
-#define SSE_RVB_UL4 6  // main launch of the two-launch form with 4 waves: slots per lane of a look-back step ...
+#define SSE_RVB_UL4 8  // main launch of the two-launch form with 4 waves: slots per lane of a look-back step ...
 #endif
 #ifndef SSE_RVB_UG4
-#define SSE_RVB_UG4 14 // ... and of a window step (its gathered-op lists hold 64 * UG ops)
+#define SSE_RVB_UG4 15 // ... and of a window step (its gathered-op lists hold 64 * UG ops)
 #endif
 
 struct RvbLds { // word offsets into lds_raw
@@ -615,10 +615,25 @@ __device__ __forceinline__ uint32_t rvb_find_constants(const DevBatch &B, const 
 // they see touch no sub-variable.  With a bit per BOND (set by the growth launch for every bond of every sub-variable) the test
 // is one LDS read and a shift per slot; the decode and the variable -> sub-variable lookups are then done once per HIT, densely
 // (64 hits per wave instruction), instead of once per slot.
+// (the map is indexed by bond + 1 — the op word's bond field as it stands — and bit 0 stays clear: an empty slot needs no test of its own)
 __device__ __forceinline__ bool bm_hit(const RvbLds &R, uint32_t wd) {
-    const uint32_t b = wd ? sse_op_bond(wd) : 0u;
-    return (wd != 0u) & (((LDSW(R.o_bm, b >> 5) >> (b & 31u)) & 1u) != 0u);
+    const uint32_t q = wd >> SSE_OP_BOND_SHIFT;
+    return ((LDSW(R.o_bm, q >> 5) >> (q & 31u)) & 1u) != 0u;
 }
+// Rows of a scan: slots p0 + 64 j, j < U, of slots [0, end) of a replica's op-string through a buffer resource — the hardware returns 0
+// for a slot at or beyond `end` (an empty slot to every consumer), the row offsets are immediates: no vector instruction per row for
+// address or bounds.  (p0 < 2^30)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ops_window(const uint32_t *ops, uint32_t end) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)ops, 0, (int)(end * 4u), 0x00020000);
+}
+template <int U>
+__device__ __forceinline__ void load_rows(__amdgpu_buffer_rsrc_t rs, uint32_t p0, uint32_t (&w)[U]) {
+    static_assert(U <= 16, "row offsets are 12-bit immediates");
+    const int v = (int)(p0 * 4u);
+#pragma unroll
+    for (int j = 0; j < U; ++j) w[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, v + j * 256, 0, 0);
+}
+
 // info word of a gathered op (sub-variables of its legs, bond kind)
 template <int W, bool CL>
 __device__ __forceinline__ uint32_t rvb_info_word(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t wd) {
@@ -639,19 +654,18 @@ __device__ __forceinline__ void rvb_last_op(const DevBatch &B, const Lds<W> &L, 
         if (sc != 0xFFFFu) atomicMax(&LDSW(R.o_last, sc), ((p + 1u) << 1) | ((sse_op_out(wd) >> 1) & 1u));
     }
 }
-// last-op search over the U rows a thread holds (row j = slot lo + j*NT + tid, valid below hi) through the bond map: the wave
+// last-op search over the U rows a lane holds (row j = slot lo + wave*64*U + j*64 + lane; slots at or beyond the span's end arrive as 0) through the bond map: the wave
 // parks its hits in its own part of the (then idle) gathered-op lists and works them off densely; a wave with more hits than its
 // part holds takes them lane by lane.  lists_free = false: the lists are in use (the rare longer look-back of rvb_fetch).
 template <int W, bool CL, int U>
-__device__ __forceinline__ void rvb_last_ops_bm(const DevBatch &B, const Lds<W> &L, const RvbLds &R, const uint32_t (&wl)[U], uint32_t lo, uint32_t hi, bool lists_free) {
-    constexpr int NT = W * 64;
+__device__ __forceinline__ void rvb_last_ops_bm(const DevBatch &B, const Lds<W> &L, const RvbLds &R, const uint32_t (&wl)[U], uint32_t lo, bool lists_free) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t p0 = lo + (uint32_t)(wave * 64 * U + lane);
     uint64_t hm[U];
     uint32_t nh = 0;
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-        const uint32_t p = lo + (uint32_t)(j * NT + tid);
-        hm[j] = sse_ballot((p < hi) & bm_hit(R, wl[j]));
+        hm[j] = sse_ballot(bm_hit(R, wl[j]));
         nh += (uint32_t)popc64(hm[j]);
     }
     const uint32_t seg = R.gcap / (uint32_t)W, s0 = (uint32_t)wave * seg;
@@ -661,7 +675,7 @@ __device__ __forceinline__ void rvb_last_ops_bm(const DevBatch &B, const Lds<W> 
         for (int j = 0; j < U; ++j) {
             if ((hm[j] >> lane) & 1ull) {
                 const uint32_t idx = run + popc64(hm[j] & lanemask_lt(lane));
-                LDSW(R.o_glp, idx) = lo + (uint32_t)(j * NT + tid);
+                LDSW(R.o_glp, idx) = p0 + (uint32_t)(j * 64);
                 LDSW(R.o_glw, idx) = wl[j];
             }
             run += (uint32_t)popc64(hm[j]);
@@ -675,7 +689,7 @@ __device__ __forceinline__ void rvb_last_ops_bm(const DevBatch &B, const Lds<W> 
     } else {
 #pragma unroll
         for (int j = 0; j < U; ++j)
-            if ((hm[j] >> lane) & 1ull) rvb_last_op<W, CL>(B, L, R, lo + (uint32_t)(j * NT + tid), wl[j]);
+            if ((hm[j] >> lane) & 1ull) rvb_last_op<W, CL>(B, L, R, p0 + (uint32_t)(j * 64), wl[j]);
     }
 }
 
@@ -688,12 +702,8 @@ template <int W, int U>
 __device__ __forceinline__ void rvb_gather_rows(const DevBatch &B, uint32_t r, uint32_t gp, uint32_t until, uint32_t M, uint32_t (&wd)[U]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
-    const uint32_t last = until < M ? until : M - 1; // inclusive
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-        const uint32_t p = gp + (uint32_t)(wave * 64 * U + j * 64 + lane);
-        wd[j] = (M != 0u && p <= last) ? ops[p] : 0u;
-    }
+    const uint32_t end = M == 0u ? 0u : (until < M ? until + 1u : M); // slots [gp, end)
+    load_rows<U>(ops_window(ops, end), gp + (uint32_t)(wave * 64 * U + lane), wd);
 }
 template <int W, bool CL, int U = 8, bool BM = false>
 __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t gp, uint32_t until,
@@ -703,16 +713,13 @@ __device__ __forceinline__ void rvb_gather(const DevBatch &B, const Lds<W> &L, c
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: keeps per-wave control flow uniform
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
     const uint32_t last = until < M ? until : M - 1; // inclusive
+    const __amdgpu_buffer_rsrc_t win = ops_window(ops, M == 0u ? 0u : last + 1u);
     uint32_t glen = 0, next = gp;
     while (M != 0u && next <= last) {
         uint32_t wn[U], info[U];
         uint64_t mm[U];
         int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const uint32_t p = next + (uint32_t)(U * NT) + (uint32_t)(wave * 64 * U + j * 64 + lane);
-            wn[j] = p <= last ? ops[p] : 0u;
-        }
+        load_rows<U>(win, next + (uint32_t)(U * NT) + (uint32_t)(wave * 64 * U + lane), wn);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             if constexpr (BM) { info[j] = 0u; mm[j] = sse_ballot(bm_hit(R, wd[j])); } // (the info words follow once the list is complete)
@@ -777,15 +784,13 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
     const uint32_t lo_b = from > (uint32_t)(UL * NT) ? from - (uint32_t)(UL * NT) : 0u; // look-back chunk [lo_b, from)
     SSE_STAMP_INIT; // diagnostic builds: 0 loads + matching, 1 compaction, 2 longer look-back, 3 states
     uint32_t wl[UL], wg[UG];
-#pragma unroll
-    for (int j = 0; j < UL; ++j) { const uint32_t p = lo_b + (uint32_t)(j * NT + tid); wl[j] = p < from ? ops[p] : 0u; }
-#pragma unroll
-    for (int j = 0; j < UG; ++j) { const uint32_t p = from + (uint32_t)(wave * 64 * UG + j * 64 + lane); wg[j] = (M != 0u && p <= last) ? ops[p] : 0u; }
-    if constexpr (BM) rvb_last_ops_bm<W, CL, UL>(B, L, R, wl, lo_b, from, true);
+    load_rows<UL>(ops_window(ops, from), lo_b + (uint32_t)(wave * 64 * UL + lane), wl);
+    load_rows<UG>(ops_window(ops, M == 0u ? 0u : last + 1u), from + (uint32_t)(wave * 64 * UG + lane), wg);
+    if constexpr (BM) rvb_last_ops_bm<W, CL, UL>(B, L, R, wl, lo_b, true);
     else {
 #pragma unroll
         for (int j = 0; j < UL; ++j)
-            if (wl[j]) rvb_last_op<W, CL>(B, L, R, lo_b + (uint32_t)(j * NT + tid), wl[j]);
+            if (wl[j]) rvb_last_op<W, CL>(B, L, R, lo_b + (uint32_t)(wave * 64 * UL + j * 64 + lane), wl[j]);
     }
     uint32_t info[UG];
     uint64_t mm[UG];
@@ -842,13 +847,12 @@ __device__ __forceinline__ void rvb_fetch(const DevBatch &B, const Lds<W> &L, co
         const uint32_t span = (uint32_t)(UL * NT);
         const uint32_t lo = hi > span ? hi - span : 0u;
         uint32_t wx[UL];
-#pragma unroll
-        for (int j = 0; j < UL; ++j) { const uint32_t p = lo + (uint32_t)(j * NT + tid); wx[j] = p < hi ? ops[p] : 0u; }
-        if constexpr (BM) rvb_last_ops_bm<W, CL, UL>(B, L, R, wx, lo, hi, false);
+        load_rows<UL>(ops_window(ops, hi), lo + (uint32_t)(wave * 64 * UL + lane), wx);
+        if constexpr (BM) rvb_last_ops_bm<W, CL, UL>(B, L, R, wx, lo, false);
         else {
 #pragma unroll
             for (int j = 0; j < UL; ++j)
-                if (wx[j]) rvb_last_op<W, CL>(B, L, R, lo + (uint32_t)(j * NT + tid), wx[j]);
+                if (wx[j]) rvb_last_op<W, CL>(B, L, R, lo + (uint32_t)(wave * 64 * UL + j * 64 + lane), wx[j]);
         }
         __syncthreads();
         hi = lo;
@@ -950,7 +954,7 @@ template <int W, bool CL, int U = 4, bool BM = false>
 __device__ __forceinline__ void rvb_state_at(const DevBatch &B, const Lds<W> &L, const RvbLds &R, uint32_t r, uint32_t from, uint32_t nsub,
                                              bool flip_by_cluster) {
     constexpr int NT = W * 64;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t *ops = B.ops + (size_t)r * B.stride;
     for (uint32_t s = tid; s < nsub; s += NT) LDSW(R.o_last, s) = 0u;
     if (tid == 0) LDSW(R.o_ctl, RC_SKIP) = 0u;
@@ -960,13 +964,12 @@ __device__ __forceinline__ void rvb_state_at(const DevBatch &B, const Lds<W> &L,
         const uint32_t span = (uint32_t)(U * NT);
         const uint32_t lo = hi > span ? hi - span : 0u;
         uint32_t wx[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) { const uint32_t p = lo + (uint32_t)(j * NT + tid); wx[j] = p < hi ? ops[p] : 0u; }
-        if constexpr (BM) rvb_last_ops_bm<W, CL, U>(B, L, R, wx, lo, hi, true); // (the gathered-op lists are idle: the gathers of this window come after)
+        load_rows<U>(ops_window(ops, hi), lo + (uint32_t)(wave * 64 * U + lane), wx);
+        if constexpr (BM) rvb_last_ops_bm<W, CL, U>(B, L, R, wx, lo, true); // (the gathered-op lists are idle: the gathers of this window come after)
         else {
 #pragma unroll
             for (int j = 0; j < U; ++j)
-                if (wx[j]) rvb_last_op<W, CL>(B, L, R, lo + (uint32_t)(j * NT + tid), wx[j]);
+                if (wx[j]) rvb_last_op<W, CL>(B, L, R, lo + (uint32_t)(wave * 64 * U + j * 64 + lane), wx[j]);
         }
         __syncthreads();
         // all found?

@@ -18,8 +18,8 @@
 
 namespace sse {
 
-// record of one attempt in HBM: [8] header (GO_*; word GO_NADJ: edges listed below, or SSE_RVB_NOADJ), bm[bmw] bond map (bit b: bond b
-// touches a sub-variable; bmw = ceil(Nb / 32)), tog[ntog], togs[ntog], sub[nsub], sfl[nsub], wfrom[nwin], wuntil[nwin], then — when the
+// record of one attempt in HBM: [8] header (GO_*; word GO_NADJ: edges listed below, or SSE_RVB_NOADJ), bm[bmw] bond map (bit b + 1: bond b
+// touches a sub-variable; bmw = ceil((Nb + 1) / 32)), tog[ntog], togs[ntog], sub[nsub], sfl[nsub], wfrom[nwin], wuntil[nwin], then — when the
 // whole record fits the part that is fetched ahead — sadj[nsub + 1], adjb[nadj]: the edges at each sub-variable (bonds_for_var), so
 // that the boundary-bond updates of the replay find them in LDS.  DevBatch::rvb_prod_stride = SSE_RVB_PROD_STRIDE + bmw words per attempt.
 #define SSE_RVB_PROD_STRIDE (8u + 4u * SSE_RVB_MAXCL + 2u * SSE_RVB_MAXSUB + 2u * SSE_RVB_MAXWIN) // header + a large area's lists
@@ -32,7 +32,7 @@ static_assert(SSE_RVB_BM_MAX <= 4u * SSE_RVB_SLOT_SET, "");
 #define SSE_RVB_REGROW 0xFFFFFFFFu // header error word: the cluster outgrew its small area, the large one takes it
 #define SSE_RVB_NOADJ 0xFFFFFFFFu
 enum { GO_NADJ = 5 };
-__host__ __device__ inline uint32_t rvb_bm_words(uint32_t Nb) { return (Nb + 31u) >> 5; }
+__host__ __device__ inline uint32_t rvb_bm_words(uint32_t Nb) { return (Nb + 32u) >> 5; } // bits 1 .. Nb: bond b at bit b + 1
 __host__ __device__ inline uint32_t rvb_gcap_main(uint32_t W) { return W <= 4u ? 64u * SSE_RVB_UG4 : 512u; } // = 64 * UG of rvb_attempt<W, CL, true>: a wave's share of a scan step
 // LDS words of the record region of the main launch: two fetched-ahead parts side by side, or one whole large record over both
 __host__ __device__ inline uint32_t rvb_region_words(uint32_t bmw) {
@@ -144,7 +144,7 @@ __device__ __forceinline__ void rvb_store_product(const DevBatch &B, uint32_t *d
         const uint32_t a0 = B.adj_start[v], deg = in ? B.adj_start[v + 1] - a0 : 0u;
         const uint32_t incl = wave_incl_scan(deg, lane), mine = run + incl - deg;
         if (in) {
-            uint32_t b = B.E + v; // the variable's own transverse (and longitudinal) bond
+            uint32_t b = B.E + v + 1u; // the variable's own transverse (and longitudinal) bond; bit index = bond + 1
             atomicOr(&LDSW(o_scr, b >> 5), 1u << (b & 31u));
             if (B.has_long) { b += B.N; atomicOr(&LDSW(o_scr, b >> 5), 1u << (b & 31u)); }
             if (with_adj) dst[o_sadj + sidx] = mine;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void rvb_store_product(const DevBatch &B, uint32_t *d
         for (uint32_t k = 0; sse_any(k < deg); ++k) {
             if (k < deg) {
                 const uint32_t b = B.adj[a0 + k];
-                atomicOr(&LDSW(o_scr, b >> 5), 1u << (b & 31u));
+                atomicOr(&LDSW(o_scr, (b + 1u) >> 5), 1u << ((b + 1u) & 31u));
                 if (with_adj) dst[o_adjb + mine + k] = b;
             }
         }
