@@ -13,6 +13,23 @@ if stats_rvb:
     shutil.copy(stats_rvb[-1], os.path.join(OUT, R + "_kernel_stats_config2_rvb.csv"))
 for f in glob.glob(os.path.join(RAW, R + "_*.json")) + glob.glob(os.path.join(RAW, R + "_*.txt")):
     shutil.copy(f, OUT)
+# RVB kernels: per-kernel counter means of the --pmc pass over tools/rvb_phases.py
+pr = sorted(glob.glob(os.path.join(RAW, "pmc_rvb", "*", "*_counter_collection.csv")), key=os.path.getmtime)
+if pr:
+    import collections
+    acc, dur = collections.defaultdict(list), collections.defaultdict(list)
+    for row in csv.DictReader(open(pr[-1])):
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "rvb_" not in k:
+            continue
+        acc[(k, row["Counter_Name"])].append(float(row["Counter_Value"]))
+        dur[k].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    with open(os.path.join(OUT, R + "_pmc_rvb_kernels.txt"), "w") as f:
+        f.write("# rocprofv3 --pmc ... -- python3 tools/rvb_phases.py (configs[2], 1024 replicas): means per launch of the two RVB kernels\n")
+        for k in sorted(dur):
+            f.write(f"{k}: {sum(dur[k]) / len(dur[k]) / 1e3:.1f} us per launch (n={len(dur[k])})\n")
+        for (k, c), v in sorted(acc.items()):
+            f.write(f"  {k:40s} {c:22s} {sum(v) / len(v):16.0f}\n")
 # registers / spills / scratch of the kernels in the SHIPPED library (read from its code objects, not from a fresh compile)
 import subprocess
 with open(os.path.join(OUT, R + "_kernel_resources.txt"), "w") as f:

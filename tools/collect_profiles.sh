@@ -18,6 +18,11 @@ python bench.py --pmj3d 16 --beta 4 --replicas 512 --equilibrate 60 --steps 20 -
 python bench.py --rvb --steps 4 --warmup 1 --equilibrate 60 > $O/${R}_bench_config2_rvb.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_rvb -- python3 bench.py --rvb --steps 4 --warmup 1 --equilibrate 60 --no-cpu-baseline > /dev/null
 python tools/rvb_phases.py > $O/${R}_rvb_sweep.txt
+python tools/rvb_phases.py --cfg 2048 >> $O/${R}_rvb_sweep.txt  # the fused kernel, for comparison
+if [ -f isingmontecarlo_amd/csrc/build/exp/lib_rvbtiming.so ]; then  # diagnostic build (EXP_TU=sweep_rvb tools/experiment_build.py rvbtiming=-DSSE_PHASE_TIMING)
+  ISINGMC_HIP_LIB=isingmontecarlo_amd/csrc/build/exp/lib_rvbtiming.so python tools/rvb_phases.py > $O/${R}_rvb_phases_diagnostic_build.txt
+fi
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-trace --output-format csv -d $O/pmc_rvb -- python3 tools/rvb_phases.py --equilibrate 40 > /dev/null
 python tools/bench_tempering.py > $O/${R}_bench_tempering_64x64.json
 python tools/bench_tempering.py --window 2.0 1.05 > $O/${R}_bench_tempering_64x64_window.json
 python tools/pass_split.py > $O/${R}_pass_split.txt
