@@ -106,6 +106,9 @@ __device__ __forceinline__ uint32_t cl_union_wave(const UFA<false> &uf, uint32_t
 
 // One launch = the cluster update (+ free spins + sampling) of every replica: the second launch of a split timestep.
 // PHASE only tags the symbol (see sweep_kernel).
+#ifndef SSE_CL_FIND_LEVELS
+#define SSE_CL_FIND_LEVELS 4 // hops of the straight-line find in front of a union
+#endif
 template <int K, bool HAS_LONG, int PHASE>
 __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, SweepArgs A) {
     constexpr int W = SSE_CLW, NT = W * 64;
@@ -267,12 +270,17 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                 const bool need = ua[j] != uc[j];
                 if (!sse_any(need) || SSE_DBG(B, 2u)) continue; // wave-uniform
                 if (need) {
-                    // three levels up from each representative, straight-line (a representative is a root or close to one: it was
+                    // SSE_CL_FIND_LEVELS hops up from each representative, straight-line (a representative is a root or close to one: it was
                     // a root when it was written); nodes found below a root are re-pointed at it on the way (they are not roots, so
                     // no link of this batch can be undone by that)
                     const uint32_t pa = LDS16B(par_b + 2u * ua[j]), pc = LDS16B(par_b + 2u * uc[j]);
-                    const uint32_t ga = LDS16B(par_b + 2u * pa), gc = LDS16B(par_b + 2u * pc);
-                    const uint32_t ta = LDS16B(par_b + 2u * ga), tc = LDS16B(par_b + 2u * gc);
+                    uint32_t ga = LDS16B(par_b + 2u * pa), gc = LDS16B(par_b + 2u * pc);
+                    uint32_t ta = LDS16B(par_b + 2u * ga), tc = LDS16B(par_b + 2u * gc);
+#pragma unroll
+                    for (int lv = 3; lv < SSE_CL_FIND_LEVELS; ++lv) { // (further levels: the candidate root moves one hop up)
+                        const uint32_t na = LDS16B(par_b + 2u * ta), nc = LDS16B(par_b + 2u * tc);
+                        ga = ta; gc = tc; ta = na; tc = nc;
+                    }
                     const bool found = (ta == ga) & (tc == gc); // ga / gc are roots (also when the chain is shorter: a root is its own parent)
                     const bool differ = ga != gc;
                     const bool link = found & differ;
@@ -283,6 +291,17 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                     if (link) LDS16B(par_b + 2u * hi) = (uint16_t)lo;
                     SSE_WAVE_FENCE();
                     const uint32_t chk = LDS16B(par_b + 2u * hi);
+#ifdef SSE_PHASE_TIMING
+                    if (wave == 3) { // diagnostic builds: why rows reach the serial routine
+                        const uint64_t nf = sse_ballot(!found), cf = sse_ballot(found & link & (chk != lo)), nd = sse_ballot(true);
+                        if (lane == (int)(__ffsll((long long)nd) - 1)) {
+                            B.dbg[(size_t)r * 16 + 8] += 1; B.dbg[(size_t)r * 16 + 12] += (uint64_t)popc64(nd);
+                            if (nf) B.dbg[(size_t)r * 16 + 9] += 1;
+                            if (!nf && cf) B.dbg[(size_t)r * 16 + 10] += 1;
+                            B.dbg[(size_t)r * 16 + 13] += (uint64_t)popc64(nf); B.dbg[(size_t)r * 16 + 14] += (uint64_t)popc64(cf);
+                        }
+                    }
+#endif
                     if ((!found | (link & (chk != lo))) && !SSE_DBG(B, 16u)) lo = cl_union_wave(uf, pa, pc);
                     // both legs' entries now name the surviving root (or the common parent found one hop up)
                     lds_cas32(adra[j], ua[j] | SSE_CL_TOUCHED, lo | SSE_CL_TOUCHED);
