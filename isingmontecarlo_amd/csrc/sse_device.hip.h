@@ -373,6 +373,19 @@ __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, ui
     return d;
 }
 
+// wave priority for the issue arbiter (s_setprio takes an immediate): x mod 4, wave-uniform
+#ifndef SSE_ROTATE_PRIO
+#define SSE_ROTATE_PRIO 2u // tiles of the trimmed diagonal kernel between two priority changes (power of two)
+#endif
+__device__ __forceinline__ void sse_set_prio(uint32_t x) {
+    switch (x & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // wave64 ballot straight from the i1 condition (HIP's __ballot(int) goes through a 0/1 integer: v_cndmask + v_cmp_ne)
 __device__ __forceinline__ uint64_t sse_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool sse_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
@@ -1457,9 +1470,13 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
     __syncthreads();
     const uint32_t p0 = LDSW(L.o_misc, MISC_LOOP_A);
     if (p0 == 0xFFFFFFFFu) { err = 2u; return 0u; } // n inconsistent with the op-string
+    // the word at the current vertex travels with the walk: the search below hands over the word it found together with the
+    // distance (one 64-bit LDS minimum), so a vertex costs one round trip to the op-string instead of three
+    const uint32_t o64 = (L.o_misc + 7u) & ~1u; // an 8-byte aligned pair inside o_misc[6, 9)
+    uint32_t cur_word = ops[p0];
     uint32_t rel0, side0;
     {
-        const Bd d0 = decode_bond<CL, W, PM>(B, L, sse_op_bond(ops[p0]));
+        const Bd d0 = decode_bond<CL, W, PM>(B, L, sse_op_bond(cur_word));
         const uint32_t k0 = d0.c != SSE_NO_VAR ? 2u : 1u;
         rel0 = __umulhi(o0.y, k0);
         side0 = (o0.z >> 31) ? 0u : 1u; // gen() true -> Inputs (directed_loop.rs:153-157)
@@ -1467,10 +1484,29 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
     uint32_t p = p0, rel = rel0, side = side0, visited = 0;
     const uint32_t max_steps = 64u * M + 1024u; // the reference's loop is unbounded (directed_loop.rs:217-301); past this the replica reports ISINGMC_ELIMIT (clearable)
     bool finished = false;
+    // A walk is one dependent chain (the longest of a batch's walks ends the launch), so what can be taken off the chain is: the
+    // random numbers (64 steps' worth at a time, lane l of every wave holding step base + l: one Philox evaluation per 64 steps instead
+    // of one per step on the single working lane), and the first search step's loads (both directions are requested before the
+    // vertex update decides which one it will be: the loads fly while thread 0 computes).
+    const bool spec = M > 2u * (uint32_t)(U * NT); // (the speculative rows then never reach the vertex itself, whose word is being rewritten)
+    uint32_t ox = 0u;
     for (uint32_t step = 1; step <= max_steps; ++step) {
+        if (((step - 1u) & 63u) == 0u) ox = rng.draw(SSE_TAG_LOOP, step + (uint32_t)lane).x;
+        const uint32_t ux = (uint32_t)__builtin_amdgcn_readlane((int)ox, (int)((step - 1u) & 63u));
+        uint32_t wf[U], wb[U];
+        if (spec) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t d = 1u + (uint32_t)(j * NT + tid);
+                uint32_t qf = p + d, qb = p + M - d;
+                if (qf >= M) qf -= M;
+                if (qb >= M) qb -= M;
+                wf[j] = ops[qf]; wb[j] = ops[qb];
+            }
+        }
         // ---- vertex update by thread 0 ----
         if (tid == 0) {
-            const uint32_t word = ops[p];
+            const uint32_t word = cur_word;
             const Bd d = decode_bond<CL, W, PM>(B, L, sse_op_bond(word));
             const uint32_t k = d.c != SSE_NO_VAR ? 2u : 1u;
             uint32_t in_e = sse_op_in(word), out_e = sse_op_out(word);
@@ -1482,8 +1518,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
                 wl[leg] = op_weight(B, sse_op_bond(word), d, i2, o2);
                 total += wl[leg];
             }
-            const uint4 o = rng.draw(SSE_TAG_LOOP, step);
-            double c = u01(o.x) * total;
+            double c = u01(ux) * total;
             uint32_t exit_leg = 2u * k - 1u;
             for (uint32_t leg = 0; leg < 2u * k; ++leg) {
                 if (c < wl[leg]) { exit_leg = leg; break; }
@@ -1497,7 +1532,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
             LDSW(L.o_misc, MISC_LOOP_A) = closed ? 1u : 0u;
             LDSW(L.o_misc, MISC_LOOP_B) = var;
             LDSW(L.o_misc, MISC_LOOP_C) = xside | (xrel << 1) | ((((xside == 1u ? out_e : in_e) >> xrel) & 1u) << 2);
-            LDSW(L.o_misc, MISC_LOOP_D) = 0xFFFFFFFFu; // best distance
+            LDSW(o64, 0) = 0xFFFFFFFFu; LDSW(o64, 1) = 0xFFFFFFFFu; // best (distance << 32 | word found there)
         }
         __syncthreads();
         visited++;
@@ -1507,33 +1542,37 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
         const uint32_t xside = info & 1u, newbit = (info >> 2) & 1u;
         const bool forward = xside == 1u;
         // ---- search the next op on worldline `var`, distance 1..M (distance M = the op itself) ----
-        uint32_t found = 0xFFFFFFFFu;
+        uint32_t found = 0xFFFFFFFFu, found_word = 0u;
         for (uint32_t d0 = 1; d0 <= M; d0 += U * NT) {
             uint32_t wd[U];
+            if (spec && d0 == 1u) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const uint32_t d = d0 + (uint32_t)(j * NT + tid);
-                wd[j] = 0u;
-                if (d <= M) {
-                    uint32_t q = forward ? p + d : p + M - d;
-                    if (q >= M) q -= M;
-                    wd[j] = ops[q];
+                for (int j = 0; j < U; ++j) wd[j] = forward ? wf[j] : wb[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const uint32_t d = d0 + (uint32_t)(j * NT + tid);
+                    wd[j] = 0u;
+                    if (d <= M) {
+                        uint32_t q = forward ? p + d : p + M - d;
+                        if (q >= M) q -= M;
+                        wd[j] = ops[q];
+                    }
                 }
             }
-            uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
-            for (int j = U - 1; j >= 0; --j) {
+            for (int j = 0; j < U; ++j) {
                 bool match = false;
                 if (wd[j]) {
                     const Bd d = decode_bond<CL, W, PM>(B, L, sse_op_bond(wd[j]));
                     match = d.a == var || d.c == var;
                 }
-                const uint64_t mm = sse_ballot(match);
-                if (mm) best = d0 + (uint32_t)(j * NT + wave * 64) + (uint32_t)(__ffsll((long long)mm) - 1);
+                // (a worldline holds an op every few hundred slots: a handful of lanes per step get here)
+                if (match) atomicMin(reinterpret_cast<unsigned long long *>(&LDSW(o64, 0)), ((unsigned long long)(d0 + (uint32_t)(j * NT + tid)) << 32) | wd[j]);
             }
-            if (best != 0xFFFFFFFFu && lane == 0) atomicMin(&LDSW(L.o_misc, MISC_LOOP_D), best);
             __syncthreads();
-            found = LDSW(L.o_misc, MISC_LOOP_D);
+            found = LDSW(o64, 1);
+            found_word = LDSW(o64, 0);
             __syncthreads();
             if (found != 0xFFFFFFFFu) break;
         }
@@ -1541,7 +1580,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
         uint32_t q = forward ? p + found : p + M - found;
         const bool wrapped = forward ? (q >= M) : (found > p);
         if (q >= M) q -= M;
-        const Bd dq = decode_bond<CL, W, PM>(B, L, sse_op_bond(ops[q]));
+        const Bd dq = decode_bond<CL, W, PM>(B, L, sse_op_bond(found_word)); // (the op itself at distance M: the word as thread 0 just left it)
         const uint32_t nrel = dq.a == var ? 0u : 1u;
         if (wrapped && tid == 0) { // directed_loop.rs:276-288
             const uint32_t wi = var >> 5, bi = var & 31;
@@ -1549,7 +1588,7 @@ __device__ __forceinline__ uint32_t loop_pass(const DevBatch &B, const Lds<W> &L
         }
         const uint32_t nside = xside ^ 1u;
         if (q == p0 && nrel == rel0 && nside == side0) { finished = true; break; } // :293
-        p = q; rel = nrel; side = nside;
+        p = q; rel = nrel; side = nside; cur_word = found_word;
     }
     if (!finished) err = 3u;
     __syncthreads();

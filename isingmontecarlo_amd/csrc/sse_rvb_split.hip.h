@@ -270,6 +270,7 @@ __global__ __launch_bounds__(W * 64, (rvb_main_waves_per_simd<W>())) void rvb_ma
     uint32_t gr = 0, nsucc = 0;
     constexpr int NPRE = (SSE_RVB_PROD_AHEAD + SSE_RVB_BM_MAX + NT - 1) / NT;
     for (uint32_t attempt = 0; attempt < updates; ++attempt) {
+        sse_set_prio(attempt / 4u + blockIdx.x); // the replicas of a CU take turns at the top issue priority (the arbiter would serve the oldest workgroup first: sse_fast.hip.h)
         uint32_t buf = PB.o_pbuf + (attempt & 1u) * small;
         uint32_t pre[NPRE]; // the next record's first words: requested now, parked in LDS at the end of this attempt
 #pragma unroll
