@@ -377,6 +377,9 @@ __device__ __forceinline__ Bd decode_bond(const DevBatch &B, const Lds<W> &L, ui
 #ifndef SSE_ROTATE_PRIO
 #define SSE_ROTATE_PRIO 2u // tiles of the trimmed diagonal kernel between two priority changes (power of two)
 #endif
+#ifndef SSE_GEN_ROTATE
+#define SSE_GEN_ROTATE 2u  // the same for the tile loops of the general kernels
+#endif
 __device__ __forceinline__ void sse_set_prio(uint32_t x) {
     switch (x & 3u) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -529,6 +532,9 @@ __device__ __forceinline__ void diagonal_pass(const DevBatch &B, const Lds<W> &L
 
     SSE_STAMP_INIT;
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
+#ifdef SSE_GEN_ROTATE
+        sse_set_prio(tile / SSE_GEN_ROTATE + blockIdx.x);
+#endif
         SSE_STAMP(11);
         uint32_t word[K];
 #pragma unroll
@@ -957,6 +963,9 @@ __device__ __forceinline__ void cluster_scan(const DevBatch &B, const Lds<W> &L,
 #pragma unroll
     for (int j = 0; j < K; ++j) { wnext[j] = row_ld(src, pbeg + j * 64 + lane); if constexpr (COMPACT) posn[j] = row_ld(cpos, pbeg + j * 64 + lane); }
     for (uint32_t p0 = pbeg; p0 < pend; p0 += TS) {
+#ifdef SSE_GEN_ROTATE
+        sse_set_prio(p0 / TS / SSE_GEN_ROTATE + blockIdx.x);
+#endif
         uint32_t word[K], pos[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) { word[j] = (p0 + j * 64 + lane < pend) ? wnext[j] : 0u; pos[j] = COMPACT ? posn[j] : p0 + j * 64 + lane; }
@@ -1128,6 +1137,9 @@ __device__ __forceinline__ void cluster_apply_cached(const DevBatch &B, const Ld
 #pragma unroll
     for (int j = 0; j < K; ++j) { wn[j] = row_ld(ops, (uint32_t)(j * NT + tid)); sn[j] = row_ld(segs, (uint32_t)(j * NT + tid)); tn[j] = G ? row_ld(segs2, (uint32_t)(j * NT + tid)) : 0u; }
     for (uint32_t p0 = 0; p0 < M; p0 += TS) {
+#ifdef SSE_GEN_ROTATE
+        sse_set_prio(p0 / TS / SSE_GEN_ROTATE + blockIdx.x);
+#endif
         uint32_t wd[K], sg[K], sh[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) { wd[j] = wn[j]; sg[j] = sn[j]; sh[j] = tn[j]; }
