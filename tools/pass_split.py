@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import _lattices as lat
 import isingmontecarlo_amd as im
+if os.environ.get("ISINGMC_HIP_LIB"):  # timing-experiment builds (tools/experiment_build.py)
+    im._build.LIB = os.environ["ISINGMC_HIP_LIB"]; im._build.build = lambda *a, **k: im._build.LIB
 L, R, beta = 32, 1024, 16.0
 cap = 1 << 18
 for name, cf, kw in (("label+lite K=4", im.CFG_FAST_LABEL, {}), ("label+lite K=2", im.CFG_FAST_LABEL, dict(waves_per_replica=4, slots_per_lane=2, waves_offdiag=16)),
