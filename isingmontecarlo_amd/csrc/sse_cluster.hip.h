@@ -291,8 +291,8 @@ __global__ __launch_bounds__(SSE_CLW * 64, 4) void cluster_kernel(DevBatch B, Sw
                     if (link) LDS16B(par_b + 2u * hi) = (uint16_t)lo;
                     SSE_WAVE_FENCE();
                     const uint32_t chk = LDS16B(par_b + 2u * hi);
-#ifdef SSE_PHASE_TIMING
-                    if (wave == 3) { // diagnostic builds: why rows reach the serial routine
+#ifdef SSE_CL_UNION_COUNTERS // (a diagnostic build of its own: the counters cost the union block a quarter of its time)
+                    if (wave == 3) { // why rows reach the serial routine
                         const uint64_t nf = sse_ballot(!found), cf = sse_ballot(found & link & (chk != lo)), nd = sse_ballot(true);
                         if (lane == (int)(__ffsll((long long)nd) - 1)) {
                             B.dbg[(size_t)r * 16 + 8] += 1; B.dbg[(size_t)r * 16 + 12] += (uint64_t)popc64(nd);
