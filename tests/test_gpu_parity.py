@@ -267,6 +267,27 @@ def test_rvb_dense_windows(oracle, cfgf):
     assert g.verify().all()
 
 
+def test_rvb_on_a_model_beyond_the_bond_map_takes_the_fused_kernel(oracle):
+    """The two-launch RVB sweep builds a per-attempt bond map in 256 words of a growth area: models with more than 8192 bonds
+    (here 64x64: 8192 edges + 4096 transverse bonds) run the fused kernel instead — same results, and launch_info says so."""
+    edges = lat.two_d_ferro(64)
+    R, beta = 2, 0.5
+    g, m, reps = make_pair(oracle, edges, 1.0, 0.0, 4096, 1 << 15, 4321, R)
+    for it in range(3):
+        g.single_diagonal_step(beta)
+        for rep in reps:
+            rep.diagonal_update(beta)
+            want = rep.n + rep.n // 2
+            if want > rep.cutoff:
+                assert rep.set_cutoff(want) == 0
+        succ, upd = g.single_rvb_sweep()
+        for r, rep in enumerate(reps):
+            assert succ[r] == rep.rvb_update(upd), (it, r)
+        assert_same(g, reps, f"64x64 rvb it={it}")
+    assert not g.launch_info()["rvb_split"]
+    assert g.verify().all()
+
+
 def test_rvb_fused_timesteps(oracle):
     edges = lat.two_d_periodic(4)
     R = 6
