@@ -251,7 +251,9 @@ __device__ __forceinline__ void diagonal_fast(const DevBatch &B, const Lds<4> &L
         // (measured: the four end at 372 / 438 / 511 / 600 us on every CU) and the last one finishes the launch alone on its SIMDs,
         // bound by latency.  Rotating the waves' priorities lets the four progress side by side: they end within 60 us of each other
         // and the launch is 11 % shorter.
+#if SSE_ROTATE_PRIO // (0: off — the arbiter's own order, for tools/wg_timeline.py)
         if ((tile & (SSE_ROTATE_PRIO - 1u)) == 0u) sse_set_prio((tile / SSE_ROTATE_PRIO) + blockIdx.x); // (the wave's slot on its SIMD, HW_ID.WAVE_ID, as the phase: no better)
+#endif
         uint32_t word[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) word[j] = wnext[j];
