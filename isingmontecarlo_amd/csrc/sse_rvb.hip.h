@@ -556,25 +556,42 @@ __device__ __forceinline__ uint32_t rvb_find_constants(const DevBatch &B, const 
     }
     __syncthreads();
     // per-variable counts (temporarily in o_zero)
+    // (Ising bond tables hold the E edges first, then the N transverse bonds: bond E + v is variable v's — no decode needed here)
     for (uint32_t p = tid; p < M; p += NT) {
         const uint32_t wd = ops[p];
-        if (!wd) continue;
-        const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
-        if (bd_kind(d) == SSE_BOND_TRANSVERSE) atomicAdd(&LDSW(R.o_zero, d.a), 1u);
+        const uint32_t v = (wd >> SSE_OP_BOND_SHIFT) - 1u - B.E; // (an empty slot wraps to a huge value)
+        if (v < N) atomicAdd(&LDSW(R.o_zero, v), 1u);
     }
     __syncthreads();
-    // exclusive prefix by one lane (N is small next to M); the counts array becomes the list of variables without
-    // constant ops: entry nz <= v is written only after entry v has been read
-    if (tid == 0) {
+    // exclusive prefix over the variables, a block of NT at a time (wave scans + the waves' totals through o_tot); the counts array
+    // becomes the list of variables without constant ops, in increasing order: entry nz <= v is written only after the whole block
+    // holding v has been read
+    {
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         uint32_t run = 0, nz = 0;
-        for (uint32_t v = 0; v < N; ++v) {
-            const uint32_t c = LDSW(R.o_zero, v);
-            LDSW(R.o_vstart, v) = run;
-            if (c == 0u) LDSW(R.o_zero, nz++) = v;
-            run += c;
+        for (uint32_t v0 = 0; v0 < N; v0 += NT) {
+            const uint32_t v = v0 + (uint32_t)tid;
+            const uint32_t c = v < N ? LDSW(R.o_zero, v) : 0u;
+            const bool z = (v < N) & (c == 0u);
+            uint32_t inc = c;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+            const uint64_t zm = sse_ballot(z);
+            if (lane == 63) LDSW(L.o_tot, wave) = inc;
+            if (lane == 0) LDSW(L.o_tot, W + wave) = (uint32_t)popc64(zm);
+            __syncthreads();
+            uint32_t cbase = 0, zbase = 0, ctot = 0, ztot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) {
+                const uint32_t a = LDSW(L.o_tot, w2), b = LDSW(L.o_tot, W + w2);
+                if (w2 < wave) { cbase += a; zbase += b; }
+                ctot += a; ztot += b;
+            }
+            if (v < N) LDSW(R.o_vstart, v) = run + cbase + inc - c;
+            if (z) LDSW(R.o_zero, nz + zbase + (uint32_t)popc64(zm & lanemask_lt(lane))) = v;
+            run += ctot; nz += ztot;
+            __syncthreads();
         }
-        LDSW(R.o_vstart, N) = run;
-        LDSW(R.o_ctl, RC_NZERO) = nz;
+        if (tid == 0) { LDSW(R.o_vstart, N) = run; LDSW(R.o_ctl, RC_NZERO) = nz; }
     }
     __syncthreads();
     const uint32_t C = LDSW(R.o_vstart, N);
@@ -582,9 +599,8 @@ __device__ __forceinline__ uint32_t rvb_find_constants(const DevBatch &B, const 
     // fill: vstart[v] doubles as the cursor and ends at the old vstart[v+1]; shift it back afterwards
     for (uint32_t p = tid; p < M; p += NT) {
         const uint32_t wd = ops[p];
-        if (!wd) continue;
-        const Bd d = decode_bond<CL, W>(B, L, sse_op_bond(wd));
-        if (bd_kind(d) == SSE_BOND_TRANSVERSE) LDSW(R.o_cps, atomicAdd(&LDSW(R.o_vstart, d.a), 1u)) = p;
+        const uint32_t v = (wd >> SSE_OP_BOND_SHIFT) - 1u - B.E;
+        if (v < N) LDSW(R.o_cps, atomicAdd(&LDSW(R.o_vstart, v), 1u)) = p;
     }
     __syncthreads();
     // vstart[v+1] := cursor[v], highest block first so that every element is read before it is overwritten
