@@ -135,6 +135,25 @@ struct RvbDraw {
         return philox4x32_10(k++, epoch_lo, replica, (SSE_TAG_RVB << 24) | (attempt & 0xFFFFFFu), k0, k1);
     }
 };
+// The same stream for a wave that runs the rule uniformly (rvb_grow): lane l evaluates draw number base + l, so one Philox evaluation
+// serves the next 64 draws of the attempt (a growth takes 4 + 2 per member) instead of one — the wave's 64 lanes would all have
+// computed the same number.
+struct RvbDrawW {
+    RvbDraw g;
+    uint4 c;       // this lane's draw: number base + lane
+    uint32_t base; // 0xFFFFFFFF: nothing cached
+    __device__ __forceinline__ void init(const RvbDraw &g0) { g = g0; base = 0xFFFFFFFFu; c = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ uint4 next(int lane) {
+        if (base == 0xFFFFFFFFu || g.k - base >= 64u) { // (uniform)
+            base = g.k;
+            c = philox4x32_10(base + (uint32_t)lane, g.epoch_lo, g.replica, (SSE_TAG_RVB << 24) | (g.attempt & 0xFFFFFFu), g.k0, g.k1);
+        }
+        const int i = (int)(g.k - base);
+        g.k++;
+        return make_uint4((uint32_t)__builtin_amdgcn_readlane((int)c.x, i), (uint32_t)__builtin_amdgcn_readlane((int)c.y, i),
+                          (uint32_t)__builtin_amdgcn_readlane((int)c.z, i), (uint32_t)__builtin_amdgcn_readlane((int)c.w, i));
+    }
+};
 
 // x^n by squaring: the same multiplication sequence as the oracle
 __device__ __forceinline__ double powi_sq(double x, uint32_t n) {
@@ -1073,11 +1092,13 @@ __device__ __forceinline__ GrowArea grow_area_large(const RvbLds &R) {
 
 // start, cluster growth, sub-variables, windows of one attempt (rvb.rs:88-232, :1054-1123); run by a whole wave, uniform
 template <int W, bool CL, bool REG>
-__device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, const RvbLds &R, const GrowArea &A, RvbDraw g, uint32_t C, uint32_t nzero,
+__device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, const RvbLds &R, const GrowArea &A, RvbDraw g0, uint32_t C, uint32_t nzero,
                                          uint32_t M, int lane) {
     const uint32_t N = B.N;
     uint32_t lerr = 0;
-    uint4 o = g.next();
+    RvbDrawW g;
+    g.init(g0);
+    uint4 o = g.next(lane);
     const uint32_t choice = __umulhi(o.x, C + nzero);
     uint32_t v0, f0;
     if (choice < C) { // the variable whose range of the position table holds `choice`: 64-way search
@@ -1092,7 +1113,7 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
         }
         v0 = lo; f0 = choice;
     } else { v0 = LDSW(R.o_zero, choice - C); f0 = SSE_NO_VAR; }
-    o = g.next();
+    o = g.next(lane);
     unsigned long long bits = (unsigned long long)o.x | ((unsigned long long)o.y << 32);
     uint32_t csize = 1;
     while ((bits & 1ull) && csize <= 64) { csize++; bits >>= 1; }
@@ -1109,12 +1130,12 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
     push_adj(v0, f0, 1.0);
     uint32_t left = csize;
     while (left > 0 && (bf.n + bn.n) > 0 && !lerr) {
-        o = g.next();
+        o = g.next(lane);
         const double f_ratio = bf.total / (bf.total + bn.total);
         bool pick_flips = u01(o.x) < f_ratio;
         if (bf.n == 0) pick_flips = false;
         if (bn.n == 0) pick_flips = true;
-        o = g.next();
+        o = g.next(lane);
         uint32_t v, flip;
         if (pick_flips) { const uint32_t idx = bf.pick(u01(o.x), lane); v = bf.var_at(idx); flip = bf.key_at(idx); bf.remove_at(idx); }
         else { const uint32_t idx = bn.pick(u01(o.x), lane); v = bn.key_at(idx); flip = SSE_NO_VAR; bn.remove_at(idx); }
@@ -1254,7 +1275,7 @@ __device__ __forceinline__ void rvb_grow(const DevBatch &B, const Lds<W> &L, con
     LDSW(A.o_out, GO_NSUB) = nsub;
     LDSW(A.o_out, GO_NWIN) = nwin;
     LDSW(A.o_out, GO_NTOG) = ntog;
-    LDSW(A.o_out, GO_K) = g.k;
+    LDSW(A.o_out, GO_K) = g.g.k;
     LDSW(A.o_out, GO_ERR) = lerr;
 }
 
