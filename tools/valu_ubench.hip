@@ -32,6 +32,22 @@ __global__ __launch_bounds__(1024, 4) void k(uint32_t *out, int iters) {
                 if (MODE == 13) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(q[u]) : "v"(q[(u + 1) & 7]));
                 if (MODE == 14) asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[u]) : "v"(f[(u + 1) & 7]));
                 if (MODE == 15) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(f[u]) : "v"(a[u]));
+                if (MODE == 16) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 17) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 18) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[u]));
+                if (MODE == 19) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 20) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[u]) : "v"(a[(u + 1) & 7]) : "vcc");
+                if (MODE == 21) asm volatile("v_cmp_eq_u32 vcc, %0, %1" : : "v"(a[u]), "v"(a[(u + 1) & 7]) : "vcc");
+                if (MODE == 22) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[u]) : "v"(a[(u + 1) & 7]), "v"(a[(u + 2) & 7]));
+                if (MODE == 23) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 24) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[u]) : "v"(a[(u + 1) & 7]), "v"(a[(u + 2) & 7]));
+                if (MODE == 26) asm volatile("v_mov_b32 %0, %1" : "=v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 27) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 28) asm volatile("v_mbcnt_hi_u32_b32 %0, %1, %0" : "+v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 29) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 30) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[u]) : "v"(a[(u + 1) & 7]));
+                if (MODE == 31) asm volatile("v_cmp_lt_u32 s[20:21], %0, %1" : : "v"(a[u]), "v"(a[(u + 1) & 7]) : "s20", "s21");
+                if (MODE == 32) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a[u]) : "v"(a[(u + 1) & 7]) : "s20", "s21");
             }
     }
     uint32_t acc = 0;
@@ -68,6 +84,22 @@ int main() {
     run<14>("v_add_f64", d, iters, 1);
     run<10>("v_cmp_lt_f64", d, iters, 1);
     run<15>("v_cvt_f64_u32", d, iters, 1);
+    run<16>("v_and_b32", d, iters, 1);
+    run<17>("v_or_b32", d, iters, 1);
+    run<27>("v_sub_u32", d, iters, 1);
+    run<30>("v_min_u32", d, iters, 1);
+    run<26>("v_mov_b32", d, iters, 1);
+    run<18>("v_lshlrev_b32 (imm)", d, iters, 1);
+    run<19>("v_lshrrev_b32 (reg)", d, iters, 1);
+    run<21>("v_cmp_eq_u32 -> vcc", d, iters, 1);
+    run<31>("v_cmp_lt_u32 -> sgpr pair", d, iters, 1);
+    run<20>("v_cndmask_b32 (vcc)", d, iters, 1);
+    run<32>("v_cndmask_b32 (sgpr pair)", d, iters, 1);
+    run<22>("v_add3_u32", d, iters, 1);
+    run<23>("v_lshl_add_u32", d, iters, 1);
+    run<24>("v_and_or_b32", d, iters, 1);
+    run<28>("v_mbcnt_hi_u32_b32", d, iters, 1);
+    run<29>("v_bcnt_u32_b32", d, iters, 1);
     run<9>("v_readlane + v_writelane (pair)", d, iters, 2);
     return 0;
 }
