@@ -507,7 +507,7 @@ static int run(isingmc_batch *b, const double *beta, uint64_t nsteps, uint32_t f
                 if (b->dev.rvb_prod) { (void)hipStreamSynchronize(b->stream); (void)hipFree(b->dev.rvb_prod); b->dev.rvb_prod = nullptr; b->dev.rvb_prod_cap = 0; }
                 void *q = nullptr;
                 if (hipMalloc(&q, (size_t)b->dev.R * updates * pstride * sizeof(uint32_t)) == hipSuccess) { b->dev.rvb_prod = (uint32_t *)q; b->dev.rvb_prod_cap = updates; b->dev.rvb_prod_stride = (uint32_t)pstride; }
-                else (void)hipGetLastError();
+                else { (void)hipGetLastError(); b->rvb_split = false; } // no room for the records: the fused kernel from now on
             }
             const DevBatch &D = b->dev;
             const uint32_t ledges = b->mode == SSE_MODE_LDS_EDGES ? D.E : 0u;
