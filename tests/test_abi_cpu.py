@@ -115,6 +115,13 @@ def test_null_handle_calls_do_not_crash():
     assert lib.isingmc_timesteps(None, 1, None, 1, 0) == -1
     assert lib.isingmc_get_n(None, None) == -1
     assert lib.isingmc_num_bonds(None) == 0
+    # the tempering entry points of round 3 (device-side decisions, sweeps at the labels' temperatures)
+    import ctypes as C
+    on = C.c_int(7)
+    assert lib.isingmc_pt_timesteps(None, 1, 1, 0) == -1
+    assert lib.isingmc_pt_set_device_decisions(None, 1) == -1
+    assert lib.isingmc_pt_get_device_decisions(None, C.byref(on)) == -1 and on.value == 7
+    assert lib.isingmc_pt_step(None, None) == -1
     lib.isingmc_destroy(None)
 
 
